@@ -1,0 +1,93 @@
+"""Input soundings of the survey's known-answer probes.
+
+These are the exact recipes the survey ran through the reference Fortran (P64
+build); the expected numbers quoted in tests/test_oracle_kat.py are the
+reference's own outputs as recorded there (6-7 significant digits).
+"""
+import numpy as np
+
+NZ = 120
+
+
+def _thermo(z):
+    T = np.maximum(210.0, 300.0 - 6.5e-3 * z)
+    p = 1e5 * (1.0 - 2.2557e-5 * z) ** 5.2559
+    es = 611.2 * np.exp(17.67 * (T - 273.15) / (T - 29.65))
+    qsat = 0.622 * es / (p - es)
+    return T, p, qsat
+
+
+def _finish(st, z, dz):
+    T, p, qv = st["t"], st["p"], st["qv"]
+    rho = 0.622 * p / (287.04 * T * (qv + 0.622))
+    st["nc"] = 1e8 / rho
+    st["nwfa"] = 11.1e6 / rho
+    st["nifa"] = 5e3 / rho
+    st["w"] = np.zeros(NZ)
+    st["dz"] = np.ascontiguousarray(dz, dtype=np.float64)
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in st.items()}
+
+
+def kat_a(mixed):
+    """KAT-A: direct mp_thompson, uniform 125 m grid."""
+    dz = np.full(NZ, 125.0)
+    z = (np.arange(1, NZ + 1) - 0.5) * 125.0
+    T, p, qsat = _thermo(z)
+    st = {k: np.zeros(NZ) for k in ("qc", "qi", "qr", "qs", "qg", "ni", "nr")}
+    st["t"], st["p"] = T, p
+    qv = 0.7 * qsat
+    m = (z > 1000) & (z < 4000)
+    qv[m] = 1.02 * qsat[m]
+    st["qc"][m] = 1e-3
+    st["qr"][m] = 5e-4
+    st["nr"][m] = 5e3
+    if mixed:
+        m = (z > 4000) & (z < 11000)
+        qv[m] = qsat[m]
+        st["qc"][m] = 2e-4
+        st["qi"][m] = 1e-4
+        st["ni"][m] = 1e5
+        st["qs"][m] = 1e-3
+        st["qg"][m] = 2e-3
+        st["qr"][m] = 1e-4
+        st["nr"][m] = 1e3
+    st["qv"] = qv
+    return _finish(st, z, dz)
+
+
+def kat_c():
+    """KAT-C: config-5 column (stretched grid, >=20 CFL substeps)."""
+    dz = 3.0 * 1.047 ** np.arange(NZ)
+    ztop = np.cumsum(dz)
+    z = ztop - 0.5 * dz
+    T, p, qsat = _thermo(z)
+    st = {k: np.zeros(NZ) for k in ("qc", "qi", "qr", "qs", "qg", "ni", "nr")}
+    st["t"], st["p"] = T, p
+    st["qv"] = 0.9 * qsat
+    m = z < 4000
+    st["qr"][m] = 5e-3
+    st["nr"][m] = 2e3
+    st["qg"][m] = 8e-3
+    m = (z > 4000) & (z < 9000)
+    st["qg"][m] = 4e-3
+    return _finish(st, z, dz)
+
+
+def kat_b():
+    """KAT-B: KiD adapter inputs (warm, nx=1).  Returns dict of Fortran-order arrays."""
+    nz = NZ
+    dz = np.full(nz, 25.0)
+    z = (np.arange(1, nz + 1) - 0.5) * 25.0
+    p = 1e5 * (1.0 - 2.2557e-5 * z) ** 5.2559
+    r_on_cp = 287.058 / 1005.0
+    exner = (p / 1e5) ** r_on_cp
+    T = 297.0 - 6.5e-3 * z
+    theta = T / exner
+    qv = 0.015 - 0.004 * z / 3000.0
+    hydro = np.zeros((2, 5, 1, nz))          # [imom, ih, i, k] == Fortran (k,i,ih,imom)
+    m = (z > 800) & (z < 2000)
+    hydro[0, 0, 0, m] = 8e-4
+    hydro[0, 1, 0, m] = 3e-4
+    hydro[1, 1, 0, m] = 2e4
+    return dict(nz=nz, nx=1, dt=10.0, p0=1e5, r_on_cp=r_on_cp, theta=theta, exner=exner, dz=dz,
+                qv=qv, hydro=hydro)
