@@ -1,0 +1,121 @@
+/*
+ * kidmp.h -- C ABI of the MI355X-native Thompson-09n column microphysics.
+ *
+ * This is the drop-in boundary for the one hot path of EnverRamirez/KiD that
+ * this project replaces.  Reference files (read-only mount /root/reference):
+ *     M: = module_mp_thompson09n.f90        W: = mphys_thompson09n.f90
+ * Every entry point names the reference interface it replaces.  Signatures use
+ * plain pointers and sizes only; the Fortran side binds them through
+ * ISO_C_BINDING (kid_amd/fortran/module_mp_thompson09n.f90).
+ *
+ * Conventions
+ *   - All reals are IEEE binary64 ("P64" build of the reference).
+ *   - A column profile is nz contiguous values, level kts first (k fastest),
+ *     i.e. exactly KiD's `theta(k,i)` storage (W:60-93).  A batch of ncol
+ *     columns is x[col*nz + k].
+ *   - Every function returns 0 on success or a negative KIDMP_E* code; it
+ *     never aborts and never throws.  kidmp_last_error() gives the text.
+ *   - One context per process and device; calls on one context are
+ *     serialised by the caller (the reference is single-threaded, M:386-430).
+ */
+#ifndef KIDMP_H
+#define KIDMP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KIDMP_OK            0
+#define KIDMP_EINVAL       -1   /* bad argument (null pointer, nz out of range ...) */
+#define KIDMP_ENODEV       -2   /* no HIP device / wrong architecture            */
+#define KIDMP_EHIP         -3   /* a HIP runtime call failed                      */
+#define KIDMP_ENOMEM       -4
+#define KIDMP_ESTATE       -5   /* context not initialised / already finalised    */
+
+#define KIDMP_MAX_NZ      256   /* levels per column supported by the kernels     */
+#define KIDMP_NRATES       36   /* process-rate diagnostics, order of M:2967-3119 */
+
+typedef struct kidmp_ctx kidmp_ctx;
+
+/* Run-time switches the reference reads from KiD modules:
+ *   iiwarm, set_Nc      `namelists` (M:22)
+ *   l_sediment          `switches`  (M:20)  gates ice/snow/graupel fall only
+ *   device              HIP device ordinal (one process per GPU)            */
+typedef struct kidmp_cfg {
+    int32_t iiwarm;
+    int32_t l_sediment;
+    double  set_Nc;        /* cloud droplet number, cm^-3 (Nt_c = set_Nc*1e6, M:381) */
+    int32_t device;
+    int32_t reserved;
+} kidmp_cfg;
+
+/* thompson_init (M:374-797): computes the gamma/rate constants on the host and
+ * builds the lookup tables (M:3698-4343) with HIP kernels into HBM. */
+int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **ctx_out);
+void kidmp_finalize(kidmp_ctx *ctx);
+const char *kidmp_last_error(const kidmp_ctx *ctx);
+
+/* mp_thompson (M:1156-3688), host arrays, one column: the compatibility entry
+ * behind the Fortran `mp_thompson` shim.  The 12 profiles are INOUT, p1d/w1d/
+ * dzq IN, ppt[4] = {pptrain, pptsnow, pptgraul, pptice} INOUT (accumulated),
+ * as in the reference dummy list (M:1156-1177). */
+int kidmp_column_step(kidmp_ctx *ctx, int32_t nz, double dt,
+                      double *qv1d, double *qc1d, double *qi1d, double *qr1d,
+                      double *qs1d, double *qg1d, double *ni1d, double *nr1d,
+                      double *nc1d, double *nwfa1d, double *nifa1d, double *t1d,
+                      const double *p1d, const double *w1d, const double *dzq,
+                      double *ppt);
+
+/* The `do i=1,nx` loop of the KiD adapter (W:54-246) as ONE batched call on
+ * host arrays x[col*nz+k]; ppt is [ncol][4] (INOUT).  rates may be NULL, else
+ * receives [ncol][KIDMP_NRATES][nz] (the save_dg values of M:2962-3124). */
+int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
+                          double *qv, double *qc, double *qi, double *qr,
+                          double *qs, double *qg, double *ni, double *nr,
+                          double *nc, double *nwfa, double *nifa, double *t,
+                          const double *p, const double *w, const double *dz,
+                          double *ppt, double *rates);
+
+/* Same, on DEVICE pointers (state resident in HBM), enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the null stream).  Asynchronous.
+ * nstep (may be NULL) receives [ncol][4] int32 substep counts (rain, ice,
+ * snow, graupel; M:3365,3447,3504,3553). */
+int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
+                            double *qv, double *qc, double *qi, double *qr,
+                            double *qs, double *qg, double *ni, double *nr,
+                            double *nc, double *nwfa, double *nifa, double *t,
+                            const double *p, const double *w, const double *dz,
+                            double *ppt, double *rates, int32_t *nstep,
+                            void *stream);
+
+/* Non-aerosol defaults for nc1d/nwfa1d/nifa1d, which the KiD wrapper leaves
+ * unset (W:36): nc=Nt_c/rho, nwfa=11.1e6/rho, nifa=naIN1*0.01/rho with
+ * rho=0.622p/(R T (qv+0.622)) (M:958-964).  Device pointers, [ncol*nz]. */
+int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n,
+                                  const double *qv, const double *t, const double *p,
+                                  double *nc, double *nwfa, double *nifa, void *stream);
+
+/* Domain sums of the surface precipitation (the analogue of the nx-means of
+ * W:248-275): out[4] (device pointer) = sum over columns of ppt[col][0..3].
+ * Multi-GPU callers all-reduce out[4] with RCCL afterwards. */
+int kidmp_reduce_ppt_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt,
+                            double *out4, void *stream);
+
+/* Introspection for parity tests: copy a lookup table / constant array to the
+ * host.  Names are the reference's (tcg_racg ... t_Efsw; cre, crg, Dr ...).
+ * Returns the number of doubles (<0 on error); out may be NULL to query. */
+int64_t kidmp_get_table(kidmp_ctx *ctx, const char *name, double *out, int64_t cap);
+int64_t kidmp_get_const(kidmp_ctx *ctx, const char *name, double *out, int64_t cap);
+
+/* Seconds spent in table construction during kidmp_init (host wall clock). */
+double kidmp_init_seconds(const kidmp_ctx *ctx);
+
+/* Name of the column-step kernel as it appears in rocprofv3 traces. */
+const char *kidmp_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KIDMP_H */

@@ -1,0 +1,317 @@
+// kidmp_capi.hip -- the C ABI of include/kidmp.h over the gfx950 kernels.
+// Host-side mirror of the reference's thompson_init / mp_thompson pair
+// (M:374, M:1156) plus the batched form of the KiD adapter loop (W:54-246).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/kidmp.h"
+#include "thompson_column.h"
+#include "thompson_host_init.h"
+#include "thompson_tables.h"
+
+using namespace kidmp;
+
+struct kidmp_ctx {
+    kidmp_cfg cfg{};
+    Consts hc{};
+    Bins hb{};
+    Consts *d_consts = nullptr;
+    Bins *d_bins = nullptr;
+    Tables tables{};
+    bool ready = false;
+    double init_s = 0.;
+    std::string err;
+    // staging for the host-array entries
+    double *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    hipStream_t stream = nullptr;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(kidmp_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg;
+    g_err = msg;
+    return code;
+}
+int hipfail(kidmp_ctx *c, hipError_t e, const char *what)
+{
+    return fail(c, KIDMP_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPTRY(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hipfail((c), e_, #x); } while (0)
+
+__global__ void k_default_aerosols(int64_t n, double Nt_c, const double *__restrict__ qv, const double *__restrict__ t,
+                                   const double *__restrict__ p, double *__restrict__ nc, double *__restrict__ nwfa,
+                                   double *__restrict__ nifa)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double rho = 0.622 * p[i] / (Rgas * t[i] * (qv[i] + 0.622));     // M:959
+    nc[i] = Nt_c / rho;                                                    // M:960
+    nwfa[i] = 11.1E6 / rho;                                                // M:961
+    nifa[i] = naIN1 * 0.01 / rho;                                          // M:962
+}
+
+// out4[s] = sum over columns of ppt[col][s]; one block, fixed order => reproducible
+__global__ void k_reduce_ppt(int64_t ncol, const double *__restrict__ ppt, double *__restrict__ out4)
+{
+    __shared__ double sh[256][4];
+    double acc[4] = {0., 0., 0., 0.};
+    for (int64_t c = threadIdx.x; c < ncol; c += blockDim.x)
+        for (int s = 0; s < 4; ++s) acc[s] += ppt[c * 4 + s];
+    for (int s = 0; s < 4; ++s) sh[threadIdx.x][s] = acc[s];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (int(threadIdx.x) < w)
+            for (int s = 0; s < 4; ++s) sh[threadIdx.x][s] += sh[threadIdx.x + w][s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) out4[threadIdx.x] = sh[0][threadIdx.x];
+}
+
+struct Named { const char *name; const double *ptr; int64_t n; };
+
+std::vector<Named> table_dir(const Tables &t)
+{
+    return {
+        {"tcg_racg", t.tcg_racg, N_RACG}, {"tmr_racg", t.tmr_racg, N_RACG}, {"tcr_gacr", t.tcr_gacr, N_RACG},
+        {"tmg_gacr", t.tmg_gacr, N_RACG}, {"tnr_racg", t.tnr_racg, N_RACG}, {"tnr_gacr", t.tnr_gacr, N_RACG},
+        {"tcs_racs1", t.tcs_racs1, N_RACS}, {"tmr_racs1", t.tmr_racs1, N_RACS}, {"tcs_racs2", t.tcs_racs2, N_RACS},
+        {"tmr_racs2", t.tmr_racs2, N_RACS}, {"tcr_sacr1", t.tcr_sacr1, N_RACS}, {"tms_sacr1", t.tms_sacr1, N_RACS},
+        {"tcr_sacr2", t.tcr_sacr2, N_RACS}, {"tms_sacr2", t.tms_sacr2, N_RACS}, {"tnr_racs1", t.tnr_racs1, N_RACS},
+        {"tnr_racs2", t.tnr_racs2, N_RACS}, {"tnr_sacr1", t.tnr_sacr1, N_RACS}, {"tnr_sacr2", t.tnr_sacr2, N_RACS},
+        {"tpi_qcfz", t.tpi_qcfz, N_QCFZ}, {"tni_qcfz", t.tni_qcfz, N_QCFZ},
+        {"tpi_qrfz", t.tpi_qrfz, N_QRFZ}, {"tpg_qrfz", t.tpg_qrfz, N_QRFZ}, {"tni_qrfz", t.tni_qrfz, N_QRFZ},
+        {"tnr_qrfz", t.tnr_qrfz, N_QRFZ},
+        {"tps_iaus", t.tps_iaus, N_IAUS}, {"tni_iaus", t.tni_iaus, N_IAUS}, {"tpi_ide", t.tpi_ide, N_IAUS},
+        {"t_Efrw", t.t_Efrw, N_EF}, {"t_Efsw", t.t_Efsw, N_EF},
+        {"racs_rec", t.racs_rec, N_RACS * RACS_REC}, {"racg_rec", t.racg_rec, N_RACG * RACG_REC},
+        {"qrfz_rec", t.qrfz_rec, N_QRFZ * QRFZ_REC},
+    };
+}
+
+std::vector<Named> const_dir(const kidmp_ctx *c)
+{
+    const Consts &h = c->hc;
+    const Bins &b = c->hb;
+    return {
+        {"Nt_c", &h.Nt_c, 1}, {"Sc3", &h.Sc3, 1}, {"D0i", &h.D0i, 1}, {"xm0s", &h.xm0s, 1}, {"xm0g", &h.xm0g, 1},
+        {"cce1", h.cce[0], 15}, {"cce2", h.cce[1], 15}, {"cce3", h.cce[2], 15}, {"cce4", h.cce[3], 15}, {"cce5", h.cce[4], 15},
+        {"ccg1", h.ccg[0], 15}, {"ccg2", h.ccg[1], 15}, {"ccg3", h.ccg[2], 15}, {"ccg4", h.ccg[3], 15}, {"ccg5", h.ccg[4], 15},
+        {"ocg1", h.ocg1, 15}, {"ocg2", h.ocg2, 15},
+        {"cie", h.cie, 7}, {"cig", h.cig, 7}, {"oig1", &h.oig1, 1}, {"oig2", &h.oig2, 1}, {"obmi", &h.obmi, 1},
+        {"cre", h.cre, 13}, {"crg", h.crg, 13}, {"ore1", &h.ore1, 1}, {"org1", &h.org1, 1}, {"org2", &h.org2, 1},
+        {"org3", &h.org3, 1}, {"obmr", &h.obmr, 1},
+        {"cse", h.cse, 18}, {"csg", h.csg, 18}, {"oams", &h.oams, 1}, {"obms", &h.obms, 1}, {"ocms", &h.ocms, 1},
+        {"cge", h.cge, 12}, {"cgg", h.cgg, 12}, {"oge1", &h.oge1, 1}, {"ogg1", &h.ogg1, 1}, {"ogg2", &h.ogg2, 1},
+        {"ogg3", &h.ogg3, 1}, {"oamg", &h.oamg, 1}, {"obmg", &h.obmg, 1}, {"ocmg", &h.ocmg, 1},
+        {"t1_qr_qc", &h.t1_qr_qc, 1}, {"t1_qr_qi", &h.t1_qr_qi, 1}, {"t2_qr_qi", &h.t2_qr_qi, 1},
+        {"t1_qg_qc", &h.t1_qg_qc, 1}, {"t1_qs_qc", &h.t1_qs_qc, 1}, {"t1_qs_qi", &h.t1_qs_qi, 1},
+        {"t1_qr_ev", &h.t1_qr_ev, 1}, {"t2_qr_ev", &h.t2_qr_ev, 1}, {"t1_qs_sd", &h.t1_qs_sd, 1},
+        {"t2_qs_sd", &h.t2_qs_sd, 1}, {"t1_qg_sd", &h.t1_qg_sd, 1}, {"t2_qg_sd", &h.t2_qg_sd, 1},
+        {"t1_qs_me", &h.t1_qs_me, 1}, {"t2_qs_me", &h.t2_qs_me, 1}, {"t1_qg_me", &h.t1_qg_me, 1},
+        {"t2_qg_me", &h.t2_qg_me, 1},
+        {"Dc", b.Dc, nbins}, {"dtc", b.dtc, nbins}, {"Di", b.Di, nbins}, {"dti", b.dti, nbins},
+        {"Dr", b.Dr, nbins}, {"dtr", b.dtr, nbins}, {"Ds", b.Ds, nbins}, {"dts", b.dts, nbins},
+        {"Dg", b.Dg, nbins}, {"dtg", b.dtg, nbins}, {"t_Nc", b.t_Nc, nbins},
+        {"r_c", b.r_c, ntb_c}, {"r_i", b.r_i, ntb_i}, {"r_r", b.r_r, ntb_r}, {"r_g", b.r_g, ntb_g},
+        {"r_s", b.r_s, ntb_s}, {"N0r_exp", b.N0r_exp, ntb_r1}, {"N0g_exp", b.N0g_exp, ntb_g1}, {"Nt_i", b.Nt_i, ntb_i1},
+    };
+}
+
+int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const void *const *ptrs, int nptr)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (ncol < 0) return fail(ctx, KIDMP_EINVAL, "kidmp: ncol < 0");
+    if (nz < 2 || nz > KIDMP_MAX_NZ) return fail(ctx, KIDMP_EINVAL, "kidmp: nz outside [2, KIDMP_MAX_NZ]");
+    if (!(dt > 0.)) return fail(ctx, KIDMP_EINVAL, "kidmp: dt must be > 0");
+    for (int i = 0; i < nptr; ++i)
+        if (!ptrs[i]) return fail(ctx, KIDMP_EINVAL, "kidmp: null array argument");
+    return KIDMP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, KIDMP_EINVAL, "kidmp_init: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, KIDMP_ENODEV, "kidmp_init: no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, KIDMP_ENODEV, "kidmp_init: bad device ordinal");
+    if (!(cfg->set_Nc > 0.)) return fail(nullptr, KIDMP_EINVAL, "kidmp_init: set_Nc must be > 0");
+    kidmp_ctx *c = new (std::nothrow) kidmp_ctx;
+    if (!c) return fail(nullptr, KIDMP_ENOMEM, "kidmp_init: out of host memory");
+    c->cfg = *cfg;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto bail = [&](int code) { kidmp_finalize(c); return code; };
+    {
+        hipError_t e = hipSetDevice(cfg->device);
+        if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return bail(KIDMP_EHIP); }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && !strstr(prop.gcnArchName, "gfx950")) {
+            g_err = std::string("kidmp_init: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
+            return bail(KIDMP_ENODEV);
+        }
+    }
+    host_init(cfg->iiwarm ? 1 : 0, cfg->l_sediment ? 1 : 0, cfg->set_Nc, c->hc, c->hb);
+    hipError_t e;
+#define INITTRY(x) do { e = (x); if (e != hipSuccess) { g_err = std::string(#x ": ") + hipGetErrorString(e); return bail(KIDMP_EHIP); } } while (0)
+    INITTRY(hipStreamCreate(&c->stream));
+    INITTRY(hipMalloc((void **)&c->d_consts, sizeof(Consts)));
+    INITTRY(hipMalloc((void **)&c->d_bins, sizeof(Bins)));
+    INITTRY(hipMemcpy(c->d_consts, &c->hc, sizeof(Consts), hipMemcpyHostToDevice));
+    INITTRY(hipMemcpy(c->d_bins, &c->hb, sizeof(Bins), hipMemcpyHostToDevice));
+    INITTRY(alloc_tables(c->tables));
+    INITTRY(build_tables(c->d_consts, c->d_bins, c->hc.iiwarm, c->tables, c->stream));
+#undef INITTRY
+    c->init_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->ready = true;
+    *out = c;
+    return KIDMP_OK;
+}
+
+void kidmp_finalize(kidmp_ctx *c)
+{
+    if (!c) return;
+    free_tables(c->tables);
+    if (c->d_consts) (void)hipFree(c->d_consts);
+    if (c->d_bins) (void)hipFree(c->d_bins);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *kidmp_last_error(const kidmp_ctx *c) { return c && !c->err.empty() ? c->err.c_str() : g_err.c_str(); }
+double kidmp_init_seconds(const kidmp_ctx *c) { return c ? c->init_s : 0.; }
+const char *kidmp_kernel_name(void) { return column_kernel_name(); }
+
+int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
+                            double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
+                            double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
+                            const double *p, const double *w, const double *dz,
+                            double *ppt, double *rates, int32_t *nstep, void *stream)
+{
+    (void)w;   // w1d only feeds activ_ncloud (is_aerosol_aware, M:2797)
+    const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
+    if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
+    StepArgs a{};
+    a.qv = qv; a.qc = qc; a.qi = qi; a.qr = qr; a.qs = qs; a.qg = qg; a.ni = ni; a.nr = nr;
+    a.nc = nc; a.nwfa = nwfa; a.nifa = nifa; a.t = t; a.p = p; a.dz = dz;
+    a.ppt = ppt; a.rates = rates; a.nstep = nstep;
+    a.consts = ctx->d_consts; a.tables = ctx->tables;
+    a.ncol = ncol; a.nz = nz; a.dt = dt;
+    HIPTRY(ctx, launch_column_step(a, (hipStream_t)stream));
+    return KIDMP_OK;
+}
+
+int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
+                          double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
+                          double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
+                          const double *p, const double *w, const double *dz, double *ppt, double *rates)
+{
+    double *io[12] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t};
+    const double *in[2] = {p, dz};
+    const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
+    if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
+    if (ncol == 0) return KIDMP_OK;
+    HIPTRY(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t prof = size_t(ncol) * size_t(nz);
+    const size_t need = (14 * prof + 4 * size_t(ncol) + (rates ? size_t(KIDMP_NRATES) * prof : 0)) * sizeof(double);
+    if (need > ctx->stage_bytes) {
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr;
+        ctx->stage_bytes = 0;
+        HIPTRY(ctx, hipMalloc((void **)&ctx->d_stage, need));
+        ctx->stage_bytes = need;
+    }
+    double *d = ctx->d_stage;
+    double *dio[12], *din[2];
+    for (int i = 0; i < 12; ++i) { dio[i] = d; d += prof; }
+    for (int i = 0; i < 2; ++i) { din[i] = d; d += prof; }
+    double *dppt = d; d += 4 * size_t(ncol);
+    double *drates = rates ? d : nullptr;
+    hipStream_t s = ctx->stream;
+    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(dio[i], io[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < 2; ++i) HIPTRY(ctx, hipMemcpyAsync(din[i], in[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPTRY(ctx, hipMemcpyAsync(dppt, ppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyHostToDevice, s));
+    int rc = kidmp_batch_step_device(ctx, ncol, nz, dt, dio[0], dio[1], dio[2], dio[3], dio[4], dio[5], dio[6], dio[7],
+                                     dio[8], dio[9], dio[10], dio[11], din[0], w, din[1], dppt, drates, nullptr, s);
+    if (rc) return rc;
+    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(io[i], dio[i], prof * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPTRY(ctx, hipMemcpyAsync(ppt, dppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (rates) HIPTRY(ctx, hipMemcpyAsync(rates, drates, size_t(KIDMP_NRATES) * prof * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPTRY(ctx, hipStreamSynchronize(s));
+    return KIDMP_OK;
+}
+
+int kidmp_column_step(kidmp_ctx *ctx, int32_t nz, double dt,
+                      double *qv1d, double *qc1d, double *qi1d, double *qr1d, double *qs1d, double *qg1d,
+                      double *ni1d, double *nr1d, double *nc1d, double *nwfa1d, double *nifa1d, double *t1d,
+                      const double *p1d, const double *w1d, const double *dzq, double *ppt)
+{
+    return kidmp_batch_step_host(ctx, 1, nz, dt, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d,
+                                 nifa1d, t1d, p1d, w1d, dzq, ppt, nullptr);
+}
+
+int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n, const double *qv, const double *t, const double *p,
+                                  double *nc, double *nwfa, double *nifa, void *stream)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (n < 0 || !qv || !t || !p || !nc || !nwfa || !nifa) return fail(ctx, KIDMP_EINVAL, "kidmp_default_aerosols_device: bad argument");
+    if (n == 0) return KIDMP_OK;
+    const int T = 256;
+    hipLaunchKernelGGL(k_default_aerosols, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, (hipStream_t)stream, n,
+                       ctx->hc.Nt_c, qv, t, p, nc, nwfa, nifa);
+    HIPTRY(ctx, hipGetLastError());
+    return KIDMP_OK;
+}
+
+int kidmp_reduce_ppt_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt, double *out4, void *stream)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (ncol < 0 || !ppt || !out4) return fail(ctx, KIDMP_EINVAL, "kidmp_reduce_ppt_device: bad argument");
+    hipLaunchKernelGGL(k_reduce_ppt, dim3(1), dim3(256), 0, (hipStream_t)stream, ncol, ppt, out4);
+    HIPTRY(ctx, hipGetLastError());
+    return KIDMP_OK;
+}
+
+int64_t kidmp_get_table(kidmp_ctx *ctx, const char *name, double *out, int64_t cap)
+{
+    if (!ctx || !ctx->ready || !name) return fail(ctx, KIDMP_ESTATE, "kidmp_get_table: bad context");
+    for (const Named &e : table_dir(ctx->tables))
+        if (!strcmp(e.name, name)) {
+            if (!out) return e.n;
+            if (cap < e.n) return fail(ctx, KIDMP_EINVAL, "kidmp_get_table: buffer too small");
+            HIPTRY(ctx, hipMemcpy(out, e.ptr, size_t(e.n) * sizeof(double), hipMemcpyDeviceToHost));
+            return e.n;
+        }
+    return fail(ctx, KIDMP_EINVAL, std::string("kidmp_get_table: unknown table ") + name);
+}
+
+int64_t kidmp_get_const(kidmp_ctx *ctx, const char *name, double *out, int64_t cap)
+{
+    if (!ctx || !ctx->ready || !name) return fail(ctx, KIDMP_ESTATE, "kidmp_get_const: bad context");
+    for (const Named &e : const_dir(ctx))
+        if (!strcmp(e.name, name)) {
+            if (!out) return e.n;
+            if (cap < e.n) return fail(ctx, KIDMP_EINVAL, "kidmp_get_const: buffer too small");
+            memcpy(out, e.ptr, size_t(e.n) * sizeof(double));
+            return e.n;
+        }
+    return fail(ctx, KIDMP_EINVAL, std::string("kidmp_get_const: unknown constant ") + name);
+}
+
+}  // extern "C"

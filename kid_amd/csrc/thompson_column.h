@@ -1,0 +1,29 @@
+// thompson_column.h -- launch interface of the gfx950 column-step kernel
+// (mp_thompson, M:1156-3688).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "thompson_params.h"
+
+namespace kidmp {
+
+constexpr int KIDMP_NRATES_ = 36;    // save_dg rates per level, order of M:2967-3119
+
+// All pointers are device pointers; profiles are x[col*nz + k] (k fastest).
+struct StepArgs {
+    double *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;   // INOUT, M:1168-1170
+    const double *p, *dz;                                                    // IN (w1d is inert, M:2797)
+    double *ppt;          // [ncol][4] rain, snow, graupel, ice (accumulated, M:1172)
+    double *rates;        // nullptr or [ncol][36][nz]
+    int32_t *nstep;       // nullptr or [ncol][4] rain, ice, snow, graupel
+    const Consts *consts; // device copy
+    Tables tables;
+    int64_t ncol;
+    int32_t nz;
+    double dt;
+};
+
+hipError_t launch_column_step(const StepArgs &a, hipStream_t s);
+const char *column_kernel_name();
+
+}  // namespace kidmp

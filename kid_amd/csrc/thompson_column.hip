@@ -1,0 +1,1532 @@
+// thompson_column.hip -- the Thompson-09n column step for gfx950 (MI355X).
+//
+// Replaces subroutine mp_thompson (M:1156-3688 of the reference's
+// module_mp_thompson09n.f90) for batches of independent columns.
+//
+// Mapping: ONE WAVEFRONT PER COLUMN, lanes over the vertical index.
+//   * KiD stores a profile as nz contiguous reals (theta(k,i), W:60), so a
+//     wave reads/writes a profile as one contiguous burst; consecutive
+//     columns are consecutive in memory, so the grid's loads are contiguous
+//     over the column index as well.
+//   * lane l owns levels k = l + 64*j, j < NJ (NJ = 2 for nz = 120).
+//   * the column's per-level state that must survive a phase boundary is
+//     staged in LDS ([slot][k], conflict-free ds_read/write_b64); the ~100
+//     values that are live inside a phase stay in VGPRs.
+//   * the few vertical couplings of the scheme are wave-level primitives:
+//       - no_micro (M:1396..1521)            ballot
+//       - k_0 = top level with T>=270.65     max-reduce      (M:1634-1637)
+//       - graupel N0 running minimum         suffix-min scan (M:1638-1654)
+//       - fall speed "carry down"            suffix propagate scan (M:3235...)
+//       - nstep, ksed1                       max-reduce      (M:3239-3246)
+//       - upwind flux sed(k+1)               lane shift      (M:3381...)
+//   * lookup tables stay in HBM/Infinity Cache; the rain-snow / rain-graupel /
+//     rain-freezing families are read as interleaved per-cell records.
+// No MFMA: pointwise transcendental rates plus a vertical sweep.
+//
+// Arithmetic: fp64 throughout (the reference's P64 build), compiled with
+// -ffp-contract=off so products and sums round as in the Fortran.
+//
+// Reference UB given defined semantics (same decisions as the oracle):
+//   U1 cloud water does not sediment (vtck/vtnck never assigned, M:3414-3425).
+//   U4 the t_Efrw/t_Efsw droplet-size index is clamped to the table.
+#include <hip/hip_runtime.h>
+
+#include "thompson_column.h"
+
+namespace kidmp {
+
+namespace {
+
+constexpr int WAVE = 64;
+
+// ---------------- wave primitives ----------------
+__device__ inline int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+__device__ inline int wave_max_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(v, d, WAVE);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// x[j] <- min over all levels at or above (lane + 64 j)
+template <int NJ>
+__device__ inline void suffix_min(double (&x)[NJ])
+{
+    const int lane = lane_id();
+    double carry = __builtin_inf();
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+        double v = x[j];
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const double o = __shfl_down(v, d, WAVE);
+            if (lane + d < WAVE) v = fmin(v, o);
+        }
+        v = fmin(v, carry);
+        x[j] = v;
+        carry = __shfl(v, 0, WAVE);
+    }
+}
+
+// v*[j] <- value at the nearest level at or above that has ok, else 0
+// (the "vtXk(k) = vtXk(k+1)" carry of M:3235, 3267, 3307, 3333)
+template <int NJ>
+__device__ inline void carry_down2(double (&a)[NJ], double (&b)[NJ], const bool (&okin)[NJ])
+{
+    const int lane = lane_id();
+    double ca = 0., cb = 0.;
+    int cok = 0;
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; --j) {
+        double va = a[j], vb = b[j];
+        int ok = okin[j] ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const double oa = __shfl_down(va, d, WAVE);
+            const double ob = __shfl_down(vb, d, WAVE);
+            const int oo = __shfl_down(ok, d, WAVE);
+            if (lane + d < WAVE && !ok) { va = oa; vb = ob; ok = oo; }
+        }
+        if (!ok) { va = ca; vb = cb; ok = cok; }
+        a[j] = ok ? va : 0.;
+        b[j] = ok ? vb : 0.;
+        ca = __shfl(va, 0, WAVE);
+        cb = __shfl(vb, 0, WAVE);
+        cok = __shfl(ok, 0, WAVE);
+    }
+}
+
+// sed(k+1) for every owned level (0 above the top slot)
+template <int NJ>
+__device__ inline void shift_from_above(const double (&s)[NJ], double (&up)[NJ])
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        double u = __shfl_down(s[j], 1, WAVE);
+        double nxt = 0.;
+        if (j + 1 < NJ) nxt = __shfl(s[j + 1 < NJ ? j + 1 : j], 0, WAVE);
+        up[j] = (lane == WAVE - 1) ? nxt : u;
+    }
+}
+
+// ---------------- scalar helpers ----------------
+// 10.**n as flang lowers real**integer (compiler-rt __powidf2), M:1766 etc.
+__device__ inline double pow10i(int b)
+{
+    const bool recip = b < 0;
+    double a = 10., r = 1.;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1. / r : r;
+}
+
+// decade search + index of M:1763-1771 and siblings
+__device__ inline int decade_idx(double x, int n0, int ntb)
+{
+    const int nic = int(lround(log10(x)));
+    int n = nic - 1;
+    for (int nn = nic - 1; nn <= nic + 1; ++nn) {
+        n = nn;
+        const double q = x / pow10i(nn);
+        if (q >= 1.0 && q < 10.0) break;
+    }
+    int idx = int(x / pow10i(n)) + 10 * (n - n0) - (n - n0);
+    idx = idx < ntb ? idx : ntb;
+    return idx > 1 ? idx : 1;
+}
+
+// Flatau et al. saturation mixing ratios, M:4656-4717
+__device__ inline double rslf(double P, double T)
+{
+    const double X = fmax(-80., T - 273.16);
+    double e = .611583699E03 + X * (.444606896E02 + X * (.143177157E01 + X * (.264224321E-1 + X * (.299291081E-3
+             + X * (.203154182E-5 + X * (.702620698E-8 + X * (.379534310E-11 + X * -.321582393E-13)))))));
+    e = fmin(e, P * 0.15);
+    return .622 * e / (P - e);
+}
+__device__ inline double rsif(double P, double T)
+{
+    const double X = fmax(-80., T - 273.16);
+    double e = .609868993E03 + X * (.499320233E02 + X * (.184672631E01 + X * (.402737184E-1 + X * (.565392987E-3
+             + X * (.521693933E-5 + X * (.307839583E-7 + X * (.105785160E-9 + X * .161444444E-12)))))));
+    e = fmin(e, P * 0.15);
+    return .622 * e / (P - e);
+}
+
+__device__ inline double visc_air(double tempc)          // M:1524-1528
+{
+    return tempc >= 0.0 ? (1.718 + 0.0049 * tempc) * 1.0E-5
+                        : (1.718 + 0.0049 * tempc - 1.2E-5 * tempc * tempc) * 1.0E-5;
+}
+
+// Field et al. (2005) fits: sum in the source's term order (M:1590-1599)
+__device__ inline double fit(const double *s, double tc, double x)
+{
+    return s[0] + s[1] * tc + s[2] * x + s[3] * tc * x + s[4] * tc * tc + s[5] * x * x
+         + s[6] * tc * tc * x + s[7] * tc * x * x + s[8] * tc * tc * tc + s[9] * x * x * x;
+}
+__device__ inline double snow_moment(const Consts &c, double tc0, double order, double smo2)
+{
+    const double a_ = pow(10.0, fit(c.sa, tc0, order));
+    const double b_ = fit(c.sb, tc0, order);
+    return a_ * pow(smo2, b_);
+}
+
+// graupel intercept before the running minimum, M:1639-1647
+__device__ inline double graupel_N0(bool use_rain, double mvd_r, double rg)
+{
+    const double xslw1 = use_rain ? 4.01 + log10(mvd_r) : 0.01;
+    const double ygra1 = 4.31 + log10(fmax(5.E-5, rg));
+    const double zans1 = 3.1 + (100. / (300. * xslw1 * ygra1 / (10. / xslw1 + 1. + 0.25 * ygra1) + 30. + 10. * ygra1));
+    const double N0 = pow(10., zans1);
+    return fmax(gonv_min, fmin(N0, gonv_max));
+}
+
+// rain number from a prescribed median volume diameter (M:1453-1454 and siblings)
+__device__ inline double nr_from_mvd(const Consts &c, double rr, double mvd)
+{
+    const double lamr = (3.0 + mu_r + 0.672) / mvd;
+    return c.crg[1] * c.org3 * rr * pow(lamr, bm_r) / am_r;
+}
+
+// LDS slots ([slot][level]); S0 = after block C, S1 = after block J, S2 = after block N
+enum Slot {
+    // S0
+    V_TEMP = 0, V_QV, V_RHO, V_RC, V_RI, V_RR, V_RS, V_RG, V_NI, V_NR, V_QVS, V_QVSI, V_SSATW, V_SSATI,
+    V_DIFFU, V_N0X,
+    // S1/S2 tendencies reuse the first slots of S0 (same lane owns the level)
+    V_TTEN = 0, V_QVTEN, V_QCTEN, V_NCTEN, V_QITEN, V_NITEN, V_QRTEN, V_NRTEN, V_QSTEN, V_QGTEN,
+    V_PRRGML, V_BOOST,
+    // S2 extras
+    V_TEMP2 = 12, V_RHO2, V_RI2, V_NI2, V_RR2, V_NR2, V_RS2, V_RG2, V_XDS, V_OCP, V_LVAP, V_N0X2,
+    NSLOT = 24
+};
+
+enum Flag { F_QC = 1, F_QI = 2, F_QR = 4, F_QS = 8, F_QG = 16 };
+
+}  // namespace
+
+template <int NJ, bool RATES>
+__global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
+{
+    constexpr int NL = NJ * WAVE;
+    __shared__ double L[NSLOT][NL];
+
+    const Consts &c = *a.consts;
+    const Tables &tb = a.tables;
+    const int lane = lane_id();
+    const int nz = a.nz;
+    const int kte = nz - 1;
+    const bool iiwarm = c.iiwarm != 0;
+    const double DT = a.dt;
+    const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
+    const double Nt_c = c.Nt_c;
+    const double obmr = c.obmr, obmi = c.obmi;
+
+    for (int64_t col = blockIdx.x; col < a.ncol; col += gridDim.x) {
+        const int64_t base = col * int64_t(nz);
+        // the 12 state profiles are read and written in place: no __restrict__ on them
+        const double *gqv = a.qv + base, *gqc = a.qc + base, *gqi = a.qi + base, *gqr = a.qr + base,
+                     *gqs = a.qs + base, *gqg = a.qg + base, *gni = a.ni + base, *gnr = a.nr + base,
+                     *gnc = a.nc + base, *gnwfa = a.nwfa + base, *gnifa = a.nifa + base, *gt = a.t + base;
+        const double *__restrict__ gp = a.p + base, *__restrict__ gdz = a.dz + base;
+        double *grates = RATES ? a.rates + col * int64_t(KIDMP_NRATES_) * nz : nullptr;
+
+        // ============ pass 0: blocks B + C, M:1387-1533 ============
+        int flg[NJ];
+        double mvdB[NJ], rgB[NJ];
+        bool warmlev[NJ];
+        bool any_micro = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = lane + WAVE * j;
+            flg[j] = 0; mvdB[j] = 0.; rgB[j] = R1; warmlev[j] = false;
+            if (k >= nz) continue;
+            const double temp = gt[k];
+            const double qv = fmax(1.E-10, gqv[k]);
+            const double pres = gp[k];
+            const double rho = 0.622 * pres / (Rgas * temp * (qv + 0.622));
+            const double qc1 = gqc[k], qi1 = gqi[k], qr1 = gqr[k], qs1 = gqs[k], qg1 = gqg[k];
+            int f = 0;
+            double rc = R1, ri = R1, ni = R2, rr = R1, nr = R2, rs = R1, rg = R1;
+
+            if (qc1 > R1) {                                  // M:1395-1418 (nc forced to Nt_c, M:1410)
+                f |= F_QC;
+                rc = qc1 * rho;
+            }
+            if (qi1 > R1) {                                  // M:1420-1445
+                f |= F_QI;
+                ri = qi1 * rho;
+                ni = fmax(R2, gni[k] * rho);
+                if (ni <= R2) {
+                    const double lami = c.cie[1] / 25.E-6;
+                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * pow(lami, bm_i));
+                }
+                double lami = pow(am_i * c.cig[1] * c.oig1 * ni / ri, obmi);
+                const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
+                if (xDi < 5.E-6) {
+                    lami = c.cie[1] / 5.E-6;
+                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * pow(lami, bm_i));
+                } else if (xDi > 300.E-6) {
+                    lami = c.cie[1] / 300.E-6;
+                    ni = c.cig[0] * c.oig2 * ri / am_i * pow(lami, bm_i);
+                }
+            }
+            if (qr1 > R1) {                                  // M:1447-1474
+                f |= F_QR;
+                rr = qr1 * rho;
+                nr = fmax(R2, gnr[k] * rho);
+                if (nr <= R2) nr = nr_from_mvd(c, rr, 1.0E-3);
+                const double lamr = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+                double mvd = (3.0 + mu_r + 0.672) / lamr;
+                if (mvd > 2.5E-3) {
+                    mvd = 2.5E-3;
+                    nr = nr_from_mvd(c, rr, mvd);
+                } else if (mvd < D0r * 0.75) {
+                    mvd = D0r * 0.75;
+                    nr = nr_from_mvd(c, rr, mvd);
+                }
+                mvdB[j] = mvd;
+            }
+            if (qs1 > R1) { f |= F_QS; rs = qs1 * rho; }     // M:1475-1483
+            if (qg1 > R1) { f |= F_QG; rg = qg1 * rho; }     // M:1484-1492
+            rgB[j] = rg;
+
+            const double tempc = temp - 273.15;              // M:1504-1521
+            const double qvs = rslf(pres, temp);
+            const double qvsi = tempc <= 0.0 ? rsif(pres, temp) : qvs;
+            double ssatw = qv / qvs - 1.;
+            double ssati = qv / qvsi - 1.;
+            if (fabs(ssatw) < eps) ssatw = 0.0;
+            if (fabs(ssati) < eps) ssati = 0.0;
+            if (f != 0 || ssati > 0.0) any_micro = true;
+            warmlev[j] = temp >= 270.65;
+            flg[j] = f;
+
+            L[V_TEMP][k] = temp;  L[V_QV][k] = qv;    L[V_RHO][k] = rho;  L[V_RC][k] = rc;
+            L[V_RI][k] = ri;      L[V_RR][k] = rr;    L[V_RS][k] = rs;    L[V_RG][k] = rg;
+            L[V_NI][k] = ni;      L[V_NR][k] = nr;    L[V_QVS][k] = qvs;  L[V_QVSI][k] = qvsi;
+            L[V_SSATW][k] = ssatw; L[V_SSATI][k] = ssati;
+            L[V_DIFFU][k] = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);   // M:1522
+        }
+
+        // ---- no_micro early return, M:1540.  Block B has already zeroed the
+        //      species at or below R1 in the caller's arrays (M:1412-1413 ...).
+        if (!__any(any_micro)) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                if (k >= nz) continue;
+                a.qc[base + k] = 0.0; a.nc[base + k] = 0.0;
+                a.qi[base + k] = 0.0; a.ni[base + k] = 0.0;
+                a.qr[base + k] = 0.0; a.nr[base + k] = 0.0;
+                a.qs[base + k] = 0.0; a.qg[base + k] = 0.0;
+                if (RATES)
+                    for (int r = 0; r < KIDMP_NRATES_; ++r) grates[int64_t(r) * nz + k] = 0.;
+            }
+            if (a.nstep && lane < 4) a.nstep[col * 4 + lane] = 0;
+            continue;
+        }
+
+        // ---- block E scan, M:1633-1649 ----
+        if (!iiwarm) {
+            int k0l = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (warmlev[j]) k0l = lane + WAVE * j;
+            const int k_0 = wave_max_i(k0l);
+            double n0[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                n0[j] = __builtin_inf();
+                if (k < nz)
+                    n0[j] = graupel_N0(k > k_0 && (flg[j] & F_QR) && mvdB[j] > 100.E-6, mvdB[j], rgB[j]);
+            }
+            suffix_min<NJ>(n0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                if (k < nz) L[V_N0X][k] = n0[j];
+            }
+        }
+
+        // ============ pass 1: blocks D-J, M:1545-2569 ============
+#pragma unroll 1
+        for (int j = 0; j < NJ; ++j) {
+            const int k = lane + WAVE * j;
+            if (k >= nz) continue;
+            const int f = flg[j];
+            const bool L_qc = f & F_QC, L_qi = f & F_QI, L_qr = f & F_QR, L_qs = f & F_QS, L_qg = f & F_QG;
+            const double temp = L[V_TEMP][k], qv = L[V_QV][k], rho = L[V_RHO][k];
+            const double rc = L[V_RC][k], ri = L[V_RI][k], rr = L[V_RR][k], rs = L[V_RS][k], rg = L[V_RG][k];
+            const double ni = L[V_NI][k], nr = L[V_NR][k];
+            const double qvsi = L[V_QVSI][k], ssatw = L[V_SSATW][k], ssati = L[V_SSATI][k];
+            const double diffu = L[V_DIFFU][k];
+            const double pres = gp[k];
+            const double nc = L_qc ? Nt_c : 2.;
+
+            // cheap thermodynamics of block C recomputed here, M:1504-1532
+            const double tempc = temp - 273.15;
+            const double rhof = sqrt(rho_not / rho);
+            const double rhof2 = sqrt(rhof);
+            const double delQvs = fmax(0.0, rslf(pres, 273.15) - qv);
+            const double visco = visc_air(tempc);
+            const double ocp = 1. / (Cp * (1. + 0.887 * qv));
+            const double vsc2 = sqrt(rho / visco);
+            const double lvap = lvap0 + (2106.0 - 4218.0) * tempc;
+            const double tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
+
+            // ---- D: snow moments, M:1546-1627 ----
+            double smob = 0., smo0 = 0., smo1 = 0., smoc = 0., smoe = 0., smof = 0.;
+            if (!iiwarm && L_qs) {
+                const double tc0 = fmin(-0.1, temp - 273.15);
+                smob = rs * c.oams;
+                const double smo2 = smob;                    // bm_s == 2 (M:1553-1554)
+                {   // 0th moment, M:1571-1574
+                    const double la = c.sa[0] + c.sa[1] * tc0 + c.sa[4] * tc0 * tc0 + c.sa[8] * tc0 * tc0 * tc0;
+                    const double b_ = c.sb[0] + c.sb[1] * tc0 + c.sb[4] * tc0 * tc0 + c.sb[8] * tc0 * tc0 * tc0;
+                    smo0 = pow(10.0, la) * pow(smo2, b_);
+                }
+                {   // 1st moment, M:1577-1587
+                    const double la = c.sa[0] + c.sa[1] * tc0 + c.sa[2] + c.sa[3] * tc0 + c.sa[4] * tc0 * tc0 + c.sa[5]
+                                    + c.sa[6] * tc0 * tc0 + c.sa[7] * tc0 + c.sa[8] * tc0 * tc0 * tc0 + c.sa[9];
+                    const double b_ = c.sb[0] + c.sb[1] * tc0 + c.sb[2] + c.sb[3] * tc0 + c.sb[4] * tc0 * tc0 + c.sb[5]
+                                    + c.sb[6] * tc0 * tc0 + c.sb[7] * tc0 + c.sb[8] * tc0 * tc0 * tc0 + c.sb[9];
+                    smo1 = pow(10.0, la) * pow(smo2, b_);
+                }
+                smoc = snow_moment(c, tc0, c.cse[0], smo2);  // M:1590-1600
+                smoe = snow_moment(c, tc0, c.cse[12], smo2); // M:1603-1613
+                smof = snow_moment(c, tc0, c.cse[15], smo2); // M:1616-1626
+            }
+
+            // ---- E (per level part): graupel slope/intercept, M:1650-1653 ----
+            double ilamg = 0., N0_g = 0.;
+            if (!iiwarm) {
+                const double N0_exp = L[V_N0X][k];
+                const double lam_exp = pow(N0_exp * am_g * c.cgg[0] / rg, c.oge1);
+                const double lamg = lam_exp * pow(c.cgg[2] * c.ogg2 * c.ogg1, c.obmg);
+                ilamg = 1. / lamg;
+                N0_g = N0_exp / (c.cgg[1] * lam_exp) * pow(lamg, c.cge[1]);
+            }
+
+            // ---- F: rain slope/intercept, M:1661-1666 ----
+            const double lamr0 = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+            const double ilamr = 1. / lamr0;
+            double mvd_r = (3.0 + mu_r + 0.672) / lamr0;
+            const double N0_r = nr * c.org2 * pow(lamr0, c.cre[1]);
+            const double lamr = 1. / ilamr;                  // "lamr = 1./ilamr(k)", M:1716 ...
+
+            // all process rates start at zero, M:1282-1363
+            double pnc_wau = 0, pnc_rcw = 0, pnc_scw = 0, pnc_gcw = 0;
+            double prr_wau = 0, prr_rcw = 0, prr_rcs = 0, prr_rcg = 0, prr_sml = 0, prr_gml = 0, prr_rci = 0;
+            double pnr_wau = 0, pnr_rcs = 0, pnr_rcg = 0, pnr_rci = 0, pnr_sml = 0, pnr_gml = 0, pnr_rcr = 0, pnr_rfz = 0;
+            double pri_inu = 0, pni_inu = 0, pri_ihm = 0, pni_ihm = 0, pri_wfz = 0, pni_wfz = 0, pri_rfz = 0,
+                   pni_rfz = 0, pri_ide = 0, pni_ide = 0, pri_rci = 0, pni_rci = 0, pni_sci = 0, pni_iau = 0;
+            const double pri_iha = 0, pni_iha = 0;           // Koop freezing needs is_aerosol_aware (M:2105)
+            double prs_iau = 0, prs_sci = 0, prs_rcs = 0, prs_scw = 0, prs_sde = 0, prs_ihm = 0, prs_ide = 0;
+            double prg_scw = 0, prg_rfz = 0, prg_gde = 0, prg_gcw = 0, prg_rci = 0, prg_rcs = 0, prg_rcg = 0, prg_ihm = 0;
+            double vts_boost = 1.5;                          // M:1751 (only read when .not.iiwarm)
+
+            // ---- G: warm-rain terms, M:1676-1726 ----
+            if (L_qr && mvd_r > D0r) {
+                const double Ef_rr = 1.0 - exp(2300.0 * (mvd_r - 1950.0E-6));
+                pnr_rcr = Ef_rr * 2.0 * nr * rr;
+            }
+            double mvd_c = D0c;
+            int nu_c = 15;
+            double lamc = 1., xDc = 0.;
+            if (L_qc) {
+                nu_c = int(lround(1000.E6 / nc)) + 2;
+                nu_c = nu_c < 15 ? nu_c : 15;
+                xDc = fmax(D0c * 1.E6, pow(rc / (am_r * nc), obmr) * 1.E6);
+                lamc = pow(nc * am_r * c.ccg[1][nu_c - 1] * c.ocg1[nu_c - 1] / rc, obmr);
+                mvd_c = (3.0 + nu_c + 0.672) / lamc;
+            }
+            if (rc > 0.01e-3) {                              // Berry & Reinhardt, M:1698-1712
+                const double Dc_g = (pow(c.ccg[2][nu_c - 1] * c.ocg2[nu_c - 1], obmr) / lamc) * 1.E6;
+                const double Dc_b = pow(xDc * xDc * xDc * Dc_g * Dc_g * Dc_g - xDc * xDc * xDc * xDc * xDc * xDc, 1. / 6.);
+                const double zq = 6.25E-6 * xDc * Dc_b * Dc_b * Dc_b - 0.4;
+                const double zeta1 = 0.5 * (zq + fabs(zq));
+                const double zeta = 0.027 * rc * zeta1;
+                const double tq = 0.5 * Dc_b - 7.5;
+                const double taud = 0.5 * (tq + fabs(tq)) + R1;
+                const double tau = 3.72 / (rc * taud);
+                prr_wau = zeta / tau;
+                prr_wau = fmin(rc * odts, prr_wau);
+                pnr_wau = prr_wau / (am_r * nu_c * D0r * D0r * D0r);
+                pnc_wau = fmin(nc * odts, prr_wau / (am_r * mvd_c * mvd_c * mvd_c));
+            }
+            if (L_qr && mvd_r > D0r && mvd_c > D0c) {        // accretion, M:1715-1726
+                int idx = 1 + int(nbins * log(mvd_r / c.Dr1) / log(c.Drn / c.Dr1));
+                idx = idx < nbins ? idx : nbins;
+                idx = idx > 1 ? idx : 1;
+                int jc = int(mvd_c * 1.E6);
+                jc = jc < 1 ? 1 : (jc > nbins ? nbins : jc);
+                const double Ef_rw = tb.t_Efrw[(idx - 1) + nbins * (jc - 1)];
+                const double coll = pow(lamr + fv_r, -c.cre[8]);
+                prr_rcw = rhof * c.t1_qr_qc * Ef_rw * rc * N0_r * coll;
+                prr_rcw = fmin(rc * odts, prr_rcw);
+                pnc_rcw = rhof * c.t1_qr_qc * Ef_rw * nc * N0_r * coll;
+                pnc_rcw = fmin(nc * odts, pnc_rcw);
+            }
+            // rain/snow/graupel scavenging of aerosols (M:1729-1740, M:1938-1959) only
+            // feeds nwfaten/nifaten under is_aerosol_aware (M:2398-2408): not computed.
+
+            // ---- H: frozen species, M:1749-2286 ----
+            if (!iiwarm) {
+                int idx_tc = int(lround(-tempc));
+                idx_tc = idx_tc < 45 ? idx_tc : 45;
+                idx_tc = idx_tc > 1 ? idx_tc : 1;
+                int idx_t = int((tempc - 2.5) / 5.) - 1;
+                idx_t = 1 > -idx_t ? 1 : -idx_t;
+                idx_t = idx_t < ntb_t ? idx_t : ntb_t;
+
+                const int idx_c = rc > c.r_c1 ? decade_idx(rc, c.nic2, ntb_c) : 1;
+                const int idx_i = ri > c.r_i1 ? decade_idx(ri, c.nii2, ntb_i) : 1;
+                const int idx_i1 = ni > c.Nt_i1 ? decade_idx(ni, c.nii3, ntb_i1) : 1;
+                int idx_r = 1, idx_r1 = ntb_r1;
+                if (rr > c.r_r1) {
+                    idx_r = decade_idx(rr, c.nir2, ntb_r);
+                    const double lam_exp = lamr * pow(c.crg[2] * c.org2 * c.org1, bm_r);
+                    const double N0_exp = c.org1 * rr / am_r * pow(lam_exp, c.cre[0]);
+                    idx_r1 = decade_idx(N0_exp, c.nir3, ntb_r1);
+                }
+                const int idx_s = rs > c.r_s1 ? decade_idx(rs, c.nis2, ntb_s) : 1;
+                int idx_g = 1, idx_g1 = ntb_g1;
+                if (rg > c.r_g1) {
+                    idx_g = decade_idx(rg, c.nig2, ntb_g);
+                    const double lamg = 1. / ilamg;
+                    const double lam_exp = lamg * pow(c.cgg[2] * c.ogg2 * c.ogg1, bm_g);
+                    const double N0_exp = c.ogg1 * rg / am_g * pow(lam_exp, c.cge[0]);
+                    idx_g1 = decade_idx(N0_exp, c.nig3, ntb_g1);
+                }
+
+                // Srivastava & Coen prefactor over ice, M:1884-1900
+                const double otemp = 1. / temp;
+                const double rvs = rho * qvsi;
+                const double h1 = otemp * (lsub * otemp * oRv - 1.);
+                const double rvs_p = rvs * otemp * (lsub * otemp * oRv - 1.);
+                const double rvs_pp = rvs * (h1 * h1 + (-2. * lsub * otemp * otemp * otemp * oRv) + otemp * otemp);
+                const double gamsc = lsub * diffu / tcond * rvs_p;
+                double alphsc = 0.5 * (gamsc / (1. + gamsc)) * (gamsc / (1. + gamsc)) * rvs_pp / rvs_p * rvs / rvs_p;
+                alphsc = fmax(1.E-9, alphsc);
+                double xsat = ssati;
+                if (fabs(xsat) < 1.E-9) xsat = 0.;
+                const double t1_subl = 4. * PI * (1.0 - alphsc * xsat + 2. * alphsc * alphsc * xsat * xsat
+                                                  - 5. * alphsc * alphsc * alphsc * xsat * xsat * xsat) / (1. + gamsc);
+
+                // riming, M:1903-1935
+                if (L_qc && mvd_c > D0c) {
+                    const double xDs = L_qs ? smoc / smob : 0.0;
+                    int jc = int(mvd_c * 1.E6);
+                    jc = jc < 1 ? 1 : (jc > nbins ? nbins : jc);
+                    if (xDs > D0s) {
+                        int idx = 1 + int(nbins * log(xDs / c.Ds1) / log(c.Dsn / c.Ds1));
+                        idx = idx < nbins ? idx : nbins;
+                        idx = idx > 1 ? idx : 1;
+                        const double Ef_sw = tb.t_Efsw[(idx - 1) + nbins * (jc - 1)];
+                        prs_scw = rhof * c.t1_qs_qc * Ef_sw * rc * smoe;
+                        pnc_scw = rhof * c.t1_qs_qc * Ef_sw * nc * smoe;
+                        pnc_scw = fmin(nc * odts, pnc_scw);
+                    }
+                    if (rg >= c.r_g1 && mvd_c > D0c) {
+                        const double xDg = (bm_g + mu_g + 1.) * ilamg;
+                        const double vtg = rhof * av_g * c.cgg[5] * c.ogg3 * pow(ilamg, bv_g);
+                        const double stoke_g = mvd_c * mvd_c * vtg * rho_w / (9. * visco * xDg);
+                        if (xDg > D0g) {
+                            double Ef_gw = 0.;
+                            if (stoke_g >= 0.4 && stoke_g <= 10.) Ef_gw = 0.55 * log10(2.51 * stoke_g);
+                            else if (stoke_g < 0.4)               Ef_gw = 0.0;
+                            else if (stoke_g > 10)                Ef_gw = 0.77;
+                            const double ig9 = pow(ilamg, c.cge[8]);
+                            prg_gcw = rhof * c.t1_qg_qc * Ef_gw * rc * N0_g * ig9;
+                            pnc_gcw = rhof * c.t1_qg_qc * Ef_gw * nc * N0_g * ig9;
+                            pnc_gcw = fmin(nc * odts, pnc_gcw);
+                        }
+                    }
+                }
+
+                // rain <-> snow / graupel collection from the tables, M:1964-2019
+                if (rr >= c.r_r1) {
+                    if (rs >= c.r_s1) {
+                        const int64_t id = (idx_s - 1) + int64_t(ntb_s) * ((idx_t - 1) + int64_t(ntb_t) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_r - 1)));
+                        const double *r = tb.racs_rec + id * RACS_REC;
+                        const double tmr_racs1 = r[0], tcr_sacr1 = r[1], tmr_racs2 = r[2], tcr_sacr2 = r[3],
+                                     tcs_racs1 = r[4], tms_sacr1 = r[5];
+                        if (temp < T_0) {
+                            prr_rcs = -(tmr_racs2 + tcr_sacr2 + tmr_racs1 + tcr_sacr1);
+                            prs_rcs = tmr_racs2 + tcr_sacr2 - tcs_racs1 - tms_sacr1;
+                            prg_rcs = tmr_racs1 + tcr_sacr1 + tcs_racs1 + tms_sacr1;
+                            prr_rcs = fmax(-rr * odts, prr_rcs);
+                            prs_rcs = fmax(-rs * odts, prs_rcs);
+                            prg_rcs = fmin((rr + rs) * odts, prg_rcs);
+                            pnr_rcs = r[6] + r[7] + r[8] + r[9];
+                        } else {
+                            prs_rcs = -tcs_racs1 - tms_sacr1 + tmr_racs2 + tcr_sacr2;
+                            prs_rcs = fmax(-rs * odts, prs_rcs);
+                            prr_rcs = -prs_rcs;
+                            pnr_rcs = r[7] + r[9];
+                        }
+                        pnr_rcs = fmin(nr * odts, pnr_rcs);
+                    }
+                    if (rg >= c.r_g1) {
+                        const int64_t id = (idx_g1 - 1) + int64_t(ntb_g1) * ((idx_g - 1) + int64_t(ntb_g) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_r - 1)));
+                        const double *r = tb.racg_rec + id * RACG_REC;
+                        if (temp < T_0) {
+                            prg_rcg = r[0] + r[1];
+                            prg_rcg = fmin(rr * odts, prg_rcg);
+                            prr_rcg = -prg_rcg;
+                            pnr_rcg = r[2] + r[3];
+                            pnr_rcg = fmin(nr * odts, pnr_rcg);
+                        } else {
+                            prr_rcg = r[4];
+                            prr_rcg = fmin(rg * odts, prr_rcg);
+                            prg_rcg = -prr_rcg;
+                            pnr_rcg = -5. * r[3];
+                        }
+                    }
+                }
+
+                if (temp < T_0) {                            // ---- below freezing, M:2025-2231 ----
+                    vts_boost = 1.0;
+                    const double rate_max = (qv - qvsi) * rho * odts * 0.999;
+
+                    if (rr > c.r_r1) {                       // Bigg freezing, M:2066-2086
+                        const int64_t id = (idx_r - 1) + int64_t(ntb_r) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_tc - 1));
+                        const double *r = tb.qrfz_rec + id * QRFZ_REC;
+                        prg_rfz = r[0] * odts;
+                        pri_rfz = r[1] * odts;
+                        pni_rfz = r[2] * odts;
+                        pnr_rfz = r[3] * odts;
+                        pnr_rfz = fmin(nr * odts, pnr_rfz);
+                    } else if (rr > R1 && temp < HGFR) {
+                        pri_rfz = rr * odts;
+                        pnr_rfz = nr * odts;
+                        pni_rfz = pnr_rfz;
+                    }
+                    if (rc > c.r_c1) {
+                        const int id = (idx_c - 1) + ntb_c * (idx_tc - 1);
+                        pri_wfz = tb.tpi_qcfz[id] * odts;
+                        pri_wfz = fmin(rc * odts, pri_wfz);
+                        pni_wfz = tb.tni_qcfz[id] * odts;
+                        pni_wfz = fmin(fmin(Nt_c * odts, pri_wfz / (2. * xm0i)), pni_wfz);
+                    } else if (rc > R1 && temp < HGFR) {
+                        pri_wfz = rc * odts;
+                        pni_wfz = nc * odts;
+                    }
+
+                    // Cooper nucleation, M:2090-2101
+                    if ((ssati >= 0.25) || (ssatw > eps && temp < 253.15)) {
+                        const double xnc = fmin(250.E3, TNO * exp(ATO * (T_0 - temp)));
+                        const double xni = ni + (pni_rfz + pni_wfz) * DT;
+                        pni_inu = 0.5 * (xnc - xni + fabs(xnc - xni)) * odts;
+                        pri_inu = fmin(rate_max, xm0i * pni_inu);
+                        pni_inu = pri_inu / xm0i;
+                    }
+
+                    if (L_qi) {                              // M:2116-2149 and M:2178-2202
+                        const double lami = pow(am_i * c.cig[1] * c.oig1 * ni / ri, obmi);
+                        const double ilami = 1. / lami;
+                        const double xDi = fmax(c.D0i, (bm_i + mu_i + 1.) * ilami);
+                        const double xmi = am_i * pow(xDi, bm_i);
+                        const double oxmi = 1. / xmi;
+                        pri_ide = C_cube * t1_subl * diffu * ssati * rvs * c.oig1 * c.cig[4] * ni * ilami;
+                        const int id = (idx_i - 1) + ntb_i * (idx_i1 - 1);
+                        if (pri_ide < 0.0) {
+                            pri_ide = fmax(fmax(-ri * odts, pri_ide), rate_max);
+                            pni_ide = pri_ide * oxmi;
+                            pni_ide = fmax(-ni * odts, pni_ide);
+                        } else {
+                            pri_ide = fmin(pri_ide, rate_max);
+                            const double frac = tb.tpi_ide[id];
+                            prs_ide = (1.0 - frac) * pri_ide;
+                            pri_ide = frac * pri_ide;
+                        }
+                        if ((idx_i == ntb_i) || (xDi > 5.0 * D0s)) {
+                            prs_iau = ri * .99 * odts;
+                            pni_iau = ni * .95 * odts;
+                        } else if (xDi < 0.1 * D0s) {
+                            prs_iau = 0.;
+                            pni_iau = 0.;
+                        } else {
+                            prs_iau = tb.tps_iaus[id] * odts;
+                            prs_iau = fmin(ri * .99 * odts, prs_iau);
+                            pni_iau = tb.tni_iaus[id] * odts;
+                            pni_iau = fmin(ni * .95 * odts, pni_iau);
+                        }
+                        if (rs >= c.r_s1) {
+                            prs_sci = c.t1_qs_qi * rhof * Ef_si * ri * smoe;
+                            pni_sci = prs_sci * oxmi;
+                        }
+                        if (rr >= c.r_r1 && mvd_r > 4. * xDi) {
+                            const double c9 = pow(lamr + fv_r, -c.cre[8]);
+                            pri_rci = rhof * c.t1_qr_qi * Ef_ri * ri * N0_r * c9;
+                            pnr_rci = rhof * c.t1_qr_qi * Ef_ri * ni * N0_r * c9;
+                            pni_rci = pri_rci * oxmi;
+                            prr_rci = rhof * c.t2_qr_qi * Ef_ri * ni * N0_r * pow(lamr + fv_r, -c.cre[7]);
+                            prr_rci = fmin(rr * odts, prr_rci);
+                            prg_rci = pri_rci + prr_rci;
+                        }
+                    }
+
+                    if (L_qs) {                              // snow deposition, M:2153-2164
+                        double C_snow = C_sqrd + (tempc + 1.5) * (C_cube - C_sqrd) / (-30. + 1.5);
+                        C_snow = fmax(C_sqrd, fmin(C_snow, C_cube));
+                        prs_sde = C_snow * t1_subl * diffu * ssati * rvs * (c.t1_qs_sd * smo1 + c.t2_qs_sd * rhof2 * vsc2 * smof);
+                        if (prs_sde < 0.) prs_sde = fmax(fmax(-rs * odts, prs_sde), rate_max);
+                        else              prs_sde = fmin(prs_sde, rate_max);
+                    }
+                    if (L_qg && ssati < -eps) {              // graupel sublimation, M:2166-2175
+                        prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g
+                                * (c.t1_qg_sd * pow(ilamg, c.cge[9]) + c.t2_qg_sd * vsc2 * rhof2 * pow(ilamg, c.cge[10]));
+                        if (prg_gde < 0.) prg_gde = fmax(fmax(-rg * odts, prg_gde), rate_max);
+                        else              prg_gde = fmin(prg_gde, rate_max);
+                    }
+
+                    if (prg_gcw > eps && tempc > -8.0) {     // Hallett-Mossop, M:2205-2218
+                        double tf = 0.;
+                        if (tempc >= -5.0 && tempc < -3.0)      tf = 0.5 * (-3.0 - tempc);
+                        else if (tempc > -8.0 && tempc < -5.0)  tf = 0.33333333 * (8.0 + tempc);
+                        pni_ihm = 3.5E8 * tf * prg_gcw;
+                        pri_ihm = xm0i * pni_ihm;
+                        prs_ihm = prs_scw / (prs_scw + prg_gcw) * pri_ihm;
+                        prg_ihm = prg_gcw / (prs_scw + prg_gcw) * pri_ihm;
+                    }
+                    if (prs_scw > 2.0 * prs_sde && prs_sde > eps) {   // rimed snow -> graupel, M:2224-2231
+                        const double r_frac = fmin(30.0, prs_scw / prs_sde);
+                        const double g_frac = fmin(0.95, 0.15 + (r_frac - 2.) * .028);
+                        vts_boost = fmin(1.5, 1.1 + (r_frac - 2.) * .016);
+                        prg_scw = g_frac * prs_scw;
+                        prs_scw = (1. - g_frac) * prs_scw;
+                    }
+                } else {                                     // ---- melting, M:2237-2281 ----
+                    if (L_qs) {
+                        prr_sml = (tempc * tcond - lvap0 * diffu * delQvs) * (c.t1_qs_me * smo1 + c.t2_qs_me * rhof2 * vsc2 * smof);
+                        prr_sml = prr_sml + 4218. * olfus * tempc * (prr_rcs + prs_scw);
+                        prr_sml = fmin(rs * odts, fmax(0., prr_sml));
+                        pnr_sml = smo0 / rs * prr_sml * pow(10.0, -0.25 * tempc);
+                        pnr_sml = fmin(smo0 * odts, pnr_sml);
+                        if (ssati < 0.) {
+                            prs_sde = C_cube * t1_subl * diffu * ssati * rvs * (c.t1_qs_sd * smo1 + c.t2_qs_sd * rhof2 * vsc2 * smof);
+                            prs_sde = fmax(-rs * odts, prs_sde);
+                        }
+                    }
+                    if (L_qg) {
+                        const double ig10 = pow(ilamg, c.cge[9]), ig11 = pow(ilamg, c.cge[10]);
+                        prr_gml = (tempc * tcond - lvap0 * diffu * delQvs) * N0_g * (c.t1_qg_me * ig10 + c.t2_qg_me * rhof2 * vsc2 * ig11);
+                        prr_gml = fmin(rg * odts, fmax(0., prr_gml));
+                        pnr_gml = N0_g * c.cgg[1] * pow(ilamg, c.cge[1]) / rg * prr_gml * pow(10.0, -0.5 * tempc);
+                        if (ssati < 0.) {
+                            prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g * (c.t1_qg_sd * ig10 + c.t2_qg_sd * vsc2 * rhof2 * ig11);
+                            prg_gde = fmax(-rg * odts, prg_gde);
+                        }
+                    }
+                    if (DT > 120.) {                         // M:2277-2281
+                        prr_rcw = prr_rcw + prs_scw + prg_gcw;
+                        prs_scw = 0.;
+                        prg_gcw = 0.;
+                    }
+                }
+            }
+
+            // ---- I: conservation limiters, M:2297-2385 ----
+            {
+                double sump = pri_inu + pri_ide + prs_ide + prs_sde + prg_gde + pri_iha;
+                double rate_max = (qv - qvsi) * odts * 0.999;
+                if ((sump > eps && sump > rate_max) || (sump < -eps && sump < rate_max)) {
+                    const double ratio = rate_max / sump;
+                    pri_inu *= ratio; pri_ide *= ratio; pni_ide *= ratio; prs_ide *= ratio;
+                    prs_sde *= ratio; prg_gde *= ratio;
+                }
+                sump = -prr_wau - pri_wfz - prr_rcw - prs_scw - prg_scw - prg_gcw;
+                rate_max = -rc * odts;
+                if (sump < rate_max && L_qc) {
+                    const double ratio = rate_max / sump;
+                    prr_wau *= ratio; pri_wfz *= ratio; prr_rcw *= ratio; prs_scw *= ratio; prg_scw *= ratio; prg_gcw *= ratio;
+                }
+                sump = pri_ide - prs_iau - prs_sci - pri_rci;
+                rate_max = -ri * odts;
+                if (sump < rate_max && L_qi) {
+                    const double ratio = rate_max / sump;
+                    pri_ide *= ratio; prs_iau *= ratio; prs_sci *= ratio; pri_rci *= ratio;
+                }
+                sump = -prg_rfz - pri_rfz - prr_rci + prr_rcs + prr_rcg;
+                rate_max = -rr * odts;
+                if (sump < rate_max && L_qr) {
+                    const double ratio = rate_max / sump;
+                    prg_rfz *= ratio; pri_rfz *= ratio; prr_rci *= ratio; prr_rcs *= ratio; prr_rcg *= ratio;
+                }
+                sump = prs_sde - prs_ihm - prr_sml + prs_rcs;
+                rate_max = -rs * odts;
+                if (sump < rate_max && L_qs) {
+                    const double ratio = rate_max / sump;
+                    prs_sde *= ratio; prs_ihm *= ratio; prr_sml *= ratio; prs_rcs *= ratio;
+                }
+                sump = prg_gde - prg_ihm - prr_gml + prg_rcg;
+                rate_max = -rg * odts;
+                if (sump < rate_max && L_qg) {
+                    const double ratio = rate_max / sump;
+                    prg_gde *= ratio; prg_ihm *= ratio; prr_gml *= ratio; prg_rcg *= ratio;
+                }
+                pri_ihm = prs_ihm + prg_ihm;                 // M:2377-2385
+                double ratio = fmin(fabs(prr_rcg), fabs(prg_rcg));
+                prr_rcg = ratio * copysign(1.0, prr_rcg);
+                prg_rcg = -prr_rcg;
+                if (temp > T_0) {
+                    ratio = fmin(fabs(prr_rcs), fabs(prs_rcs));
+                    prr_rcs = ratio * copysign(1.0, prr_rcs);
+                    prs_rcs = -prr_rcs;
+                }
+            }
+
+            // ---- J: tendencies and number re-balancing, M:2393-2567 ----
+            const double orho = 1. / rho;
+            const double lfus2 = lsub - lvap;
+            const double qc1 = L_qc ? gqc[k] : 0.0, nc1 = L_qc ? gnc[k] : 0.0;     // as cleaned by block B
+            const double qi1 = L_qi ? gqi[k] : 0.0, ni1 = L_qi ? gni[k] : 0.0;
+            const double qr1 = L_qr ? gqr[k] : 0.0, nr1 = L_qr ? gnr[k] : 0.0;
+
+            const double qvten = (-pri_inu - pri_iha - pri_ide - prs_ide - prs_sde - prg_gde) * orho;
+            const double qcten = (-prr_wau - pri_wfz - prr_rcw - prs_scw - prg_scw - prg_gcw) * orho;
+            double ncten = (-pnc_wau - pnc_rcw - pni_wfz - pnc_scw - pnc_gcw) * orho;
+            {
+                const double xrc = fmax(R1, (qc1 + qcten * DT) * rho);
+                double xnc = fmax(2., (nc1 + ncten * DT) * rho);
+                if (xrc > R1) {
+                    int nu = int(lround(1000.E6 / xnc)) + 2;
+                    nu = nu < 15 ? nu : 15;
+                    double lc = pow(xnc * am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] / rc, obmr);
+                    const double xD = (bm_r + nu + 1.) / lc;
+                    if (xD < D0c) {
+                        lc = c.cce[1][nu - 1] / D0c;
+                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * pow(lc, bm_r);
+                        ncten = (xnc - nc1 * rho) * odts * orho;
+                    } else if (xD > D0r * 2.) {
+                        lc = c.cce[1][nu - 1] / (D0r * 2.);
+                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * pow(lc, bm_r);
+                        ncten = (xnc - nc1 * rho) * odts * orho;
+                    }
+                } else {
+                    ncten = -nc1 * odts;
+                }
+                xnc = fmax(0., (nc1 + ncten * DT) * rho);
+                if (xnc > Nt_c_max) ncten = (Nt_c_max - nc1 * rho) * odts * orho;
+            }
+
+            const double qiten = (pri_inu + pri_iha + pri_ihm + pri_wfz + pri_rfz + pri_ide - prs_iau - prs_sci - pri_rci) * orho;
+            double niten = (pni_inu + pni_iha + pni_ihm + pni_wfz + pni_rfz + pni_ide - pni_iau - pni_sci - pni_rci) * orho;
+            {
+                const double xri = fmax(R1, (qi1 + qiten * DT) * rho);
+                double xni = fmax(R2, (ni1 + niten * DT) * rho);
+                if (xri > R1) {
+                    double lami = pow(am_i * c.cig[1] * c.oig1 * xni / xri, obmi);
+                    const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
+                    if (xDi < 5.E-6) {
+                        lami = c.cie[1] / 5.E-6;
+                        xni = fmin(499.e3, c.cig[0] * c.oig2 * xri / am_i * pow(lami, bm_i));
+                        niten = (xni - ni1 * rho) * odts * orho;
+                    } else if (xDi > 300.E-6) {
+                        lami = c.cie[1] / 300.E-6;
+                        xni = c.cig[0] * c.oig2 * xri / am_i * pow(lami, bm_i);
+                        niten = (xni - ni1 * rho) * odts * orho;
+                    }
+                } else {
+                    niten = -ni1 * odts;
+                }
+                xni = fmax(0., (ni1 + niten * DT) * rho);
+                if (xni > 499.E3) niten = (499.E3 - ni1 * rho) * odts * orho;
+            }
+
+            double qrten = (prr_wau + prr_rcw + prr_sml + prr_gml + prr_rcs + prr_rcg - prg_rfz - pri_rfz - prr_rci) * orho;
+            double nrten = (pnr_wau + pnr_sml + pnr_gml - (pnr_rfz + pnr_rcr + pnr_rcg + pnr_rcs + pnr_rci)) * orho;
+            {
+                const double xrr = fmax(R1, (qr1 + qrten * DT) * rho);
+                double xnr = fmax(R2, (nr1 + nrten * DT) * rho);
+                if (xrr > R1) {
+                    const double lr = pow(am_r * c.crg[2] * c.org2 * xnr / xrr, obmr);
+                    mvd_r = (3.0 + mu_r + 0.672) / lr;
+                    if (mvd_r > 2.5E-3) {
+                        xnr = nr_from_mvd(c, xrr, 2.5E-3);
+                        nrten = (xnr - nr1 * rho) * odts * orho;
+                    } else if (mvd_r < D0r * 0.75) {
+                        xnr = nr_from_mvd(c, xrr, D0r * 0.75);
+                        nrten = (xnr - nr1 * rho) * odts * orho;
+                    }
+                } else {
+                    qrten = -qr1 * odts;
+                    nrten = -nr1 * odts;
+                }
+            }
+
+            const double qsten = (prs_iau + prs_sde + prs_sci + prs_scw + prs_rcs + prs_ide - prs_ihm - prr_sml) * orho;
+            const double qgten = (prg_scw + prg_rfz + prg_gde + prg_rcg + prg_gcw + prg_rci + prg_rcs - prg_ihm - prr_gml) * orho;
+            double tten;
+            if (temp < T_0) {
+                tten = (lsub * ocp * (pri_inu + pri_ide + prs_ide + prs_sde + prg_gde + pri_iha)
+                      + lfus2 * ocp * (pri_wfz + pri_rfz + prg_rfz + prs_scw + prg_scw + prg_gcw + prg_rcs + prs_rcs + prr_rci + prg_rcg)) * orho;
+            } else {
+                tten = (lfus * ocp * (-prr_sml - prr_gml - prr_rcg - prr_rcs) + lsub * ocp * (prs_sde + prg_gde)) * orho;
+            }
+
+            L[V_TTEN][k] = tten;   L[V_QVTEN][k] = qvten; L[V_QCTEN][k] = qcten; L[V_NCTEN][k] = ncten;
+            L[V_QITEN][k] = qiten; L[V_NITEN][k] = niten; L[V_QRTEN][k] = qrten; L[V_NRTEN][k] = nrten;
+            L[V_QSTEN][k] = qsten; L[V_QGTEN][k] = qgten; L[V_PRRGML][k] = prr_gml; L[V_BOOST][k] = vts_boost;
+
+            if (RATES) {                                     // save_dg order of M:2967-3119 (two of them in pass 2)
+                double *g = grates + k;
+                if (!iiwarm) {
+                    const double v[30] = {pri_inu, pri_ide, prs_ide, prs_sde, prg_gde, pri_wfz, prs_scw, prg_scw, prg_gcw, pri_ihm,
+                                          pri_rfz, prs_iau, prs_sci, pri_rci, pni_inu, pni_ihm, pni_wfz, pni_rfz, pni_ide, pni_iau,
+                                          pni_sci, pni_rci, prr_sml, prr_gml, pnr_rcs, pnr_rcg, pnr_rci, pnr_sml, pnr_gml, pnr_rfz};
+#pragma unroll
+                    for (int r = 0; r < 30; ++r) g[int64_t(r) * nz] = v[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 30; ++r) g[int64_t(r) * nz] = 0.;
+                }
+                g[int64_t(30) * nz] = prr_wau;
+                g[int64_t(31) * nz] = prr_rcw;
+                g[int64_t(33) * nz] = pnr_wau;
+                g[int64_t(35) * nz] = pnr_rcr;
+            }
+        }
+
+        // ============ pass 2: blocks K, L(snow), rain PSD, M, N; M:2574-2960 ============
+        double mvdK[NJ];
+        int flg2[NJ];
+#pragma unroll 1
+        for (int j = 0; j < NJ; ++j) {
+            const int k = lane + WAVE * j;
+            flg2[j] = 0; mvdK[j] = 0.; warmlev[j] = false;
+            if (k >= nz) continue;
+            const int f = flg[j];
+            const double t1 = gt[k], qv1 = gqv[k], pres = gp[k];
+            const double qc1 = (f & F_QC) ? gqc[k] : 0.0;
+            const double qi1 = (f & F_QI) ? gqi[k] : 0.0, ni1 = (f & F_QI) ? gni[k] : 0.0;
+            const double qr1 = (f & F_QR) ? gqr[k] : 0.0, nr1 = (f & F_QR) ? gnr[k] : 0.0;
+            const double qs1 = (f & F_QS) ? gqs[k] : 0.0, qg1 = (f & F_QG) ? gqg[k] : 0.0;
+            double tten = L[V_TTEN][k], qvten = L[V_QVTEN][k], qcten = L[V_QCTEN][k], ncten = L[V_NCTEN][k];
+            const double qiten = L[V_QITEN][k], niten = L[V_NITEN][k];
+            double qrten = L[V_QRTEN][k], nrten = L[V_NRTEN][k];
+            const double qsten = L[V_QSTEN][k], qgten = L[V_QGTEN][k], prr_gml = L[V_PRRGML][k];
+            double nwfaten = 0.;
+
+            // ---- K, M:2575-2655 ----
+            double temp = t1 + DT * tten;
+            double otemp = 1. / temp;
+            double tempc = temp - 273.15;
+            double qv = fmax(1.E-10, qv1 + DT * qvten);
+            double rho = 0.622 * pres / (Rgas * temp * (qv + 0.622));
+            double rhof = sqrt(rho_not / rho);
+            double rhof2 = sqrt(rhof);
+            double qvs = rslf(pres, temp);
+            double ssatw = qv / qvs - 1.;
+            if (fabs(ssatw) < eps) ssatw = 0.0;
+            double diffu = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);
+            double visco = visc_air(tempc);
+            double vsc2 = sqrt(rho / visco);
+            double lvap = lvap0 + (2106.0 - 4218.0) * tempc;
+            double tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
+            double ocp = 1. / (Cp * (1. + 0.887 * qv));
+            const double lvt2 = lvap * lvap * ocp * oRv * otemp * otemp;
+
+            int f2 = 0;
+            double rc = R1, nc = 2., ri = R1, ni = R2, rr = R1, nr = R2, rs = R1, rg = R1;
+            if ((qc1 + qcten * DT) > R1) { rc = (qc1 + qcten * DT) * rho; nc = Nt_c; f2 |= F_QC; }
+            if ((qi1 + qiten * DT) > R1) {
+                ri = (qi1 + qiten * DT) * rho;
+                ni = fmax(R2, (ni1 + niten * DT) * rho);
+                f2 |= F_QI;
+            }
+            if ((qr1 + qrten * DT) > R1) {
+                rr = (qr1 + qrten * DT) * rho;
+                nr = fmax(R2, (nr1 + nrten * DT) * rho);
+                f2 |= F_QR;
+                const double lr = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+                double mvd = (3.0 + mu_r + 0.672) / lr;
+                if (mvd > 2.5E-3)           { mvd = 2.5E-3;      nr = nr_from_mvd(c, rr, mvd); }
+                else if (mvd < D0r * 0.75)  { mvd = D0r * 0.75;  nr = nr_from_mvd(c, rr, mvd); }
+                mvdK[j] = mvd;
+            }
+            if ((qs1 + qsten * DT) > R1) { rs = (qs1 + qsten * DT) * rho; f2 |= F_QS; }
+            if ((qg1 + qgten * DT) > R1) { rg = (qg1 + qgten * DT) * rho; f2 |= F_QG; }
+            flg2[j] = f2;
+            warmlev[j] = temp >= 270.65;                     // for k_0 of M:2718-2721
+
+            // ---- L: snow moments needed later (smoc/smob only), M:2663-2698 ----
+            double xDs = 0.;
+            if (!iiwarm && (f2 & F_QS)) {
+                const double tc0 = fmin(-0.1, temp - 273.15);
+                const double smob = rs * c.oams;
+                const double smoc = snow_moment(c, tc0, c.cse[0], smob);
+                xDs = smoc / smob;                           // smod (M:2701-2711) feeds nothing
+            }
+
+            // rain PSD, M:2745-2750
+            const double lamrK = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+            const double ilamr = 1. / lamrK;
+            const double N0_r = nr * c.org2 * pow(lamrK, c.cre[1]);
+
+            // ---- M: saturation adjustment, M:2780-2873 ----
+            double orho = 1. / rho;
+            double prw_vcd = 0.;
+            if ((ssatw > eps) || (ssatw < -eps && (f2 & F_QC))) {
+                double clap = (qv - qvs) / (1. + lvt2 * qvs);
+                for (int n = 0; n < 3; ++n) {
+                    const double ex = exp(lvt2 * clap);
+                    const double fcd = qvs * ex - qv + clap;
+                    const double dfcd = qvs * lvt2 * ex + 1.;
+                    clap = clap - fcd / dfcd;
+                }
+                const double xrc = rc + clap * rho;
+                double pnc_wcd = 0.;
+                if (xrc > R1) {
+                    prw_vcd = clap * odt;
+                    if (clap > eps) {
+                        const double xnc = Nt_c;
+                        pnc_wcd = 0.5 * (xnc - nc + fabs(xnc - nc)) * odts * orho;
+                    }
+                } else {
+                    prw_vcd = -rc * orho * odt;
+                    pnc_wcd = -nc * orho * odt;
+                }
+                qvten = qvten - prw_vcd;
+                qcten = qcten + prw_vcd;
+                ncten = ncten + pnc_wcd;
+                nwfaten = nwfaten - pnc_wcd;
+                tten = tten + lvap * ocp * prw_vcd;
+                rc = fmax(R1, (qc1 + DT * qcten) * rho);
+                qv = fmax(1.E-10, qv1 + DT * qvten);
+                temp = t1 + DT * tten;
+                rho = 0.622 * pres / (Rgas * temp * (qv + 0.622));
+                qvs = rslf(pres, temp);
+                ssatw = qv / qvs - 1.;
+            }
+
+            // ---- N: rain evaporation, M:2880-2960 ----
+            double prv_rev = 0., pnr_rev = 0.;
+            if ((ssatw < -eps) && (f2 & F_QR) && (!(prw_vcd > 0.))) {
+                tempc = temp - 273.15;
+                otemp = 1. / temp;
+                orho = 1. / rho;
+                rhof = sqrt(rho_not * orho);
+                rhof2 = sqrt(rhof);
+                diffu = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);
+                visco = visc_air(tempc);
+                vsc2 = sqrt(rho / visco);
+                lvap = lvap0 + (2106.0 - 4218.0) * tempc;
+                tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
+                ocp = 1. / (Cp * (1. + 0.887 * qv));
+
+                const double rvs = rho * qvs;
+                const double h1 = otemp * (lvap * otemp * oRv - 1.);
+                const double rvs_p = rvs * otemp * (lvap * otemp * oRv - 1.);
+                const double rvs_pp = rvs * (h1 * h1 + (-2. * lvap * otemp * otemp * otemp * oRv) + otemp * otemp);
+                const double gamsc = lvap * diffu / tcond * rvs_p;
+                double alphsc = 0.5 * (gamsc / (1. + gamsc)) * (gamsc / (1. + gamsc)) * rvs_pp / rvs_p * rvs / rvs_p;
+                alphsc = fmax(1.E-9, alphsc);
+                const double xsat = fmin(-1.E-9, ssatw);
+                const double t1_evap = 2. * PI * (1.0 - alphsc * xsat + 2. * alphsc * alphsc * xsat * xsat
+                                                  - 5. * alphsc * alphsc * alphsc * xsat * xsat * xsat) / (1. + gamsc);
+                const double lamr = 1. / ilamr;
+                if (qv / qvs < 0.95 && rr * orho <= 1.E-8) {
+                    prv_rev = rr * orho * odts;
+                } else {
+                    prv_rev = t1_evap * diffu * (-ssatw) * N0_r * rvs
+                            * (c.t1_qr_ev * pow(ilamr, c.cre[9]) + c.t2_qr_ev * vsc2 * rhof2 * pow(lamr + 0.5 * fv_r, -c.cre[10]));
+                    const double rate_max = fmin((rr * orho * odts), (qvs - qv) * odts);
+                    prv_rev = fmin(rate_max, prv_rev * orho);
+                    if (prr_gml > 0.0) {
+                        const double eva_factor = fmin(1.0, 0.01 + (0.99 - 0.01) * (tempc / 20.0));
+                        prv_rev = prv_rev * eva_factor;
+                    }
+                }
+                pnr_rev = fmin(nr * 0.99 * orho * odts, prv_rev * nr / rr);
+
+                qrten = qrten - prv_rev;
+                qvten = qvten + prv_rev;
+                nrten = nrten - pnr_rev;
+                nwfaten = nwfaten + pnr_rev;
+                tten = tten - lvap * ocp * prv_rev;
+
+                rr = fmax(R1, (qr1 + DT * qrten) * rho);
+                qv = fmax(1.E-10, qv1 + DT * qvten);
+                nr = fmax(R2, (nr1 + DT * nrten) * rho);
+                temp = t1 + DT * tten;
+                rho = 0.622 * pres / (Rgas * temp * (qv + 0.622));
+            }
+            if (RATES) {
+                grates[int64_t(32) * nz + k] = prv_rev;
+                grates[int64_t(34) * nz + k] = pnr_rev;
+            }
+
+            // qv and the (inert) aerosol numbers are final here: blocks O-Q do not touch them
+            a.qv[base + k] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
+            a.nwfa[base + k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (gnwfa[k] + nwfaten * DT)));   // M:3628
+            a.nifa[base + k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (gnifa[k] + 0. * DT)));       // M:3630
+
+            L[V_TTEN][k] = tten;   L[V_QCTEN][k] = qcten; L[V_NCTEN][k] = ncten;
+            L[V_QRTEN][k] = qrten; L[V_NRTEN][k] = nrten;
+            L[V_TEMP2][k] = temp;  L[V_RHO2][k] = rho;    L[V_RI2][k] = ri;  L[V_NI2][k] = ni;
+            L[V_RR2][k] = rr;      L[V_NR2][k] = nr;      L[V_RS2][k] = rs;  L[V_RG2][k] = rg;
+            L[V_XDS][k] = xDs;     L[V_OCP][k] = ocp;     L[V_LVAP][k] = lvap;
+        }
+
+        // ============ pass 3: fall speeds, M:3206-3354 ============
+        double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
+        double odz[NJ], orho_[NJ], tmp2[NJ];
+        bool ok[NJ];
+        int nstep_r = 0, nstep_i = 0, nstep_s = 0, nstep_g = 0;
+        int ksed_r = 0, ksed_i = 0, ksed_s = 0, ksed_g = 0;
+
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int k = lane + WAVE * j;
+            vtr[j] = vtnr[j] = vti[j] = vtni[j] = vts[j] = vtg[j] = 0.;
+            odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = false;
+            if (k >= nz) continue;
+            const double rho = L[V_RHO2][k];
+            odz[j] = 1. / gdz[k];
+            orho_[j] = 1. / rho;
+            tmp2[j] = L[V_TEMP2][k];
+            const double rr = L[V_RR2][k];
+            if (rr > R1) {                                   // M:3221-3233
+                ok[j] = true;
+                const double rhof = sqrt(rho_not / rho);
+                const double nr = L[V_NR2][k];
+                const double lamr = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+                vtr[j] = rhof * av_r * c.crg[5] * c.org3 * pow(lamr, c.cre[2]) * pow(lamr + fv_r, -c.cre[5]);
+                vtnr[j] = rhof * av_r * c.crg[6] / c.crg[11] * pow(lamr, c.cre[11]) * pow(lamr + fv_r, -c.cre[6]);
+            }
+        }
+        carry_down2<NJ>(vtr, vtnr, ok);
+        {
+            int ns = 0, ks = 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                if (k >= nz) continue;
+                const double vm = fmax(vtr[j], vtnr[j]);
+                if (vm > 1.E-3) {                            // M:3239-3243
+                    ks = k;
+                    const double delta_tp = gdz[k] / vm;
+                    const int n1 = int(DT / delta_tp + 1.);
+                    ns = n1 > ns ? n1 : ns;
+                }
+            }
+            nstep_r = wave_max_i(ns);
+            ksed_r = wave_max_i(ks);
+            if (ksed_r == kte) ksed_r = kte - 1;
+        }
+        double onstep_r = 1.0, onstep_i = 1.0, onstep_s = 1.0, onstep_g = 1.0;
+        if (nstep_r > 0) onstep_r = 1. / double(nstep_r);    // M:3246
+
+        if (!iiwarm) {
+            // graupel slope from the second running minimum, M:2717-2737
+            {
+                int k0l = 0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (warmlev[j]) k0l = lane + WAVE * j;
+                const int k_0 = wave_max_i(k0l);
+                double n0[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    n0[j] = __builtin_inf();
+                    if (k < nz)
+                        n0[j] = graupel_N0(k > k_0 && (flg2[j] & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L[V_RG2][k]);
+                }
+                suffix_min<NJ>(n0);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    if (k < nz) L[V_N0X2][k] = n0[j];
+                }
+            }
+
+            // ice, M:3253-3278
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                ok[j] = false;
+                if (k >= nz) continue;
+                const double ri = L[V_RI2][k];
+                if (ri > R1) {
+                    ok[j] = true;
+                    const double rhof = sqrt(rho_not / L[V_RHO2][k]);
+                    const double lami = pow(am_i * c.cig[1] * c.oig1 * L[V_NI2][k] / ri, obmi);
+                    const double ilami = 1. / lami;
+                    const double pw = pow(ilami, bv_i);
+                    vti[j] = rhof * av_i * c.cig[2] * c.oig2 * pw;
+                    vtni[j] = rhof * av_i * c.cig[5] / c.cig[6] * pw;
+                }
+            }
+            carry_down2<NJ>(vti, vtni, ok);
+            {
+                int ns = 0, ks = 0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    if (k < nz && vti[j] > 1.E-3) {
+                        ks = k;
+                        const int n1 = int(DT / (gdz[k] / vti[j]) + 1.);
+                        ns = n1 > ns ? n1 : ns;
+                    }
+                }
+                nstep_i = wave_max_i(ns);
+                ksed_i = wave_max_i(ks);
+                if (ksed_i == kte) ksed_i = kte - 1;
+                if (nstep_i > 0) onstep_i = 1. / double(nstep_i);
+            }
+
+            // snow, M:3284-3317
+            double dummy[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                ok[j] = false; dummy[j] = 0.;
+                if (k >= nz) continue;
+                if (L[V_RS2][k] > R1) {
+                    ok[j] = true;
+                    const double rhof = sqrt(rho_not / L[V_RHO2][k]);
+                    const double xDs = L[V_XDS][k];
+                    const double Mrat = 1. / xDs;
+                    double ils1 = 1. / (Mrat * Lam0 + fv_s);
+                    double ils2 = 1. / (Mrat * Lam1 + fv_s);
+                    const double mm = pow(Mrat, mu_s);
+                    const double t1_vts = Kap0 * c.csg[3] * pow(ils1, c.cse[3]);
+                    const double t2_vts = Kap1 * mm * c.csg[9] * pow(ils2, c.cse[9]);
+                    ils1 = 1. / (Mrat * Lam0);
+                    ils2 = 1. / (Mrat * Lam1);
+                    const double t3_vts = Kap0 * c.csg[0] * pow(ils1, c.cse[0]);
+                    const double t4_vts = Kap1 * mm * c.csg[6] * pow(ils2, c.cse[6]);
+                    const double v = rhof * av_s * (t1_vts + t2_vts) / (t3_vts + t4_vts);
+                    const double boost = L[V_BOOST][k];
+                    if (tmp2[j] > (T_0 + 0.1))
+                        vts[j] = fmax(v * boost, v * ((vtr[j] - v * boost) / (tmp2[j] - T_0)));
+                    else
+                        vts[j] = v * boost;
+                }
+            }
+            carry_down2<NJ>(vts, dummy, ok);
+            {
+                int ns = 0, ks = 0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    if (k < nz && vts[j] > 1.E-3) {
+                        ks = k;
+                        const int n1 = int(DT / (gdz[k] / vts[j]) + 1.);
+                        ns = n1 > ns ? n1 : ns;
+                    }
+                }
+                nstep_s = wave_max_i(ns);
+                ksed_s = wave_max_i(ks);
+                if (ksed_s == kte) ksed_s = kte - 1;
+                if (nstep_s > 0) onstep_s = 1. / double(nstep_s);
+            }
+
+            // graupel, M:3321-3343
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                ok[j] = false; dummy[j] = 0.;
+                if (k >= nz) continue;
+                const double rg = L[V_RG2][k];
+                if (rg > R1) {
+                    ok[j] = true;
+                    const double rhof = sqrt(rho_not / L[V_RHO2][k]);
+                    const double N0_exp = L[V_N0X2][k];
+                    const double lam_exp = pow(N0_exp * am_g * c.cgg[0] / rg, c.oge1);
+                    const double lamg = lam_exp * pow(c.cgg[2] * c.ogg2 * c.ogg1, c.obmg);
+                    const double ilamg = 1. / lamg;
+                    const double v = rhof * av_g * c.cgg[5] * c.ogg3 * pow(ilamg, bv_g);
+                    vtg[j] = tmp2[j] > T_0 ? fmax(v, vtr[j]) : v;
+                }
+            }
+            carry_down2<NJ>(vtg, dummy, ok);
+            {
+                int ns = 0, ks = 0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    if (k < nz && vtg[j] > 1.E-3) {
+                        ks = k;
+                        const int n1 = int(DT / (gdz[k] / vtg[j]) + 1.);
+                        ns = n1 > ns ? n1 : ns;
+                    }
+                }
+                nstep_g = wave_max_i(ns);
+                ksed_g = wave_max_i(ks);
+                if (ksed_g == kte) ksed_g = kte - 1;
+                if (nstep_g > 0) onstep_g = 1. / double(nstep_g);
+            }
+        }
+        // nstep = NINT(1./onstep), M:3365 etc. (0 -> 1)
+        nstep_r = int(lround(1. / onstep_r));
+        nstep_i = int(lround(1. / onstep_i));
+        nstep_s = int(lround(1. / onstep_s));
+        nstep_g = int(lround(1. / onstep_g));
+        if (a.nstep && lane == 0) {
+            a.nstep[col * 4 + 0] = nstep_r; a.nstep[col * 4 + 1] = nstep_i;
+            a.nstep[col * 4 + 2] = nstep_s; a.nstep[col * 4 + 3] = nstep_g;
+        }
+
+        // ============ pass 4: sedimentation sweeps, M:3365-3578 ============
+        double ppt_r = 0., ppt_s = 0., ppt_g = 0., ppt_i = 0.;
+        {   // rain (never gated by l_sediment), M:3365-3399
+            double r[NJ], n[NJ], qt[NJ], nt[NJ], sr[NJ], sn[NJ], ur[NJ], un[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                const bool in = k < nz;
+                r[j] = in ? L[V_RR2][k] : 0.;   n[j] = in ? L[V_NR2][k] : 0.;
+                qt[j] = in ? L[V_QRTEN][k] : 0.; nt[j] = in ? L[V_NRTEN][k] : 0.;
+            }
+            for (int s = 0; s < nstep_r; ++s) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { sr[j] = vtr[j] * r[j]; sn[j] = vtnr[j] * n[j]; }
+                shift_from_above<NJ>(sr, ur);
+                shift_from_above<NJ>(sn, un);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    if (k == kte) {
+                        qt[j] = qt[j] - sr[j] * odz[j] * onstep_r * orho_[j];
+                        nt[j] = nt[j] - sn[j] * odz[j] * onstep_r * orho_[j];
+                        r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onstep_r);
+                        n[j] = fmax(R2, n[j] - sn[j] * odz[j] * DT * onstep_r);
+                    } else if (k <= ksed_r) {
+                        qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_r * orho_[j];
+                        nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_r * orho_[j];
+                        r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_r);
+                        n[j] = fmax(R2, n[j] + (un[j] - sn[j]) * odz[j] * DT * onstep_r);
+                    }
+                }
+                if (r[0] > R1 * 10.) ppt_r = ppt_r + sr[0] * DT * onstep_r;   // meaningful on lane 0 (k = kts)
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int k = lane + WAVE * j;
+                if (k < nz) { L[V_QRTEN][k] = qt[j]; L[V_NRTEN][k] = nt[j]; }
+            }
+        }
+        if (!iiwarm && c.l_sediment) {
+            {   // ice, M:3447-3480
+                double r[NJ], n[NJ], qt[NJ], nt[NJ], sr[NJ], sn[NJ], ur[NJ], un[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    const bool in = k < nz;
+                    r[j] = in ? L[V_RI2][k] : 0.;   n[j] = in ? L[V_NI2][k] : 0.;
+                    qt[j] = in ? L[V_QITEN][k] : 0.; nt[j] = in ? L[V_NITEN][k] : 0.;
+                }
+                for (int s = 0; s < nstep_i; ++s) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { sr[j] = vti[j] * r[j]; sn[j] = vtni[j] * n[j]; }
+                    shift_from_above<NJ>(sr, ur);
+                    shift_from_above<NJ>(sn, un);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int k = lane + WAVE * j;
+                        if (k == kte) {
+                            qt[j] = qt[j] - sr[j] * odz[j] * onstep_i * orho_[j];
+                            nt[j] = nt[j] - sn[j] * odz[j] * onstep_i * orho_[j];
+                            r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onstep_i);
+                            n[j] = fmax(R2, n[j] - sn[j] * odz[j] * DT * onstep_i);
+                        } else if (k <= ksed_i) {
+                            qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_i * orho_[j];
+                            nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_i * orho_[j];
+                            r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_i);
+                            n[j] = fmax(R2, n[j] + (un[j] - sn[j]) * odz[j] * DT * onstep_i);
+                        }
+                    }
+                    if (r[0] > R1 * 10.) ppt_i = ppt_i + sr[0] * DT * onstep_i;
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    if (k < nz) { L[V_QITEN][k] = qt[j]; L[V_NITEN][k] = nt[j]; }
+                }
+            }
+            // snow (M:3504-3529) and graupel (M:3553-3578): mass only
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                double r[NJ], qt[NJ], sr[NJ], ur[NJ];
+                const int slot_r = sp == 0 ? V_RS2 : V_RG2, slot_t = sp == 0 ? V_QSTEN : V_QGTEN;
+                const int nst = sp == 0 ? nstep_s : nstep_g, ksed = sp == 0 ? ksed_s : ksed_g;
+                const double onst = sp == 0 ? onstep_s : onstep_g;
+                double pp = 0.;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    const bool in = k < nz;
+                    r[j] = in ? L[slot_r][k] : 0.;
+                    qt[j] = in ? L[slot_t][k] : 0.;
+                }
+                for (int s = 0; s < nst; ++s) {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) sr[j] = (sp == 0 ? vts[j] : vtg[j]) * r[j];
+                    shift_from_above<NJ>(sr, ur);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int k = lane + WAVE * j;
+                        if (k == kte) {
+                            qt[j] = qt[j] - sr[j] * odz[j] * onst * orho_[j];
+                            r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onst);
+                        } else if (k <= ksed) {
+                            qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onst * orho_[j];
+                            r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onst);
+                        }
+                    }
+                    if (r[0] > R1 * 10.) pp = pp + sr[0] * DT * onst;
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int k = lane + WAVE * j;
+                    if (k < nz) L[slot_t][k] = qt[j];
+                }
+                if (sp == 0) ppt_s = pp; else ppt_g = pp;
+            }
+        }
+        if (lane == 0) {                                     // precipitation is accumulated (INOUT, M:1172)
+            double *pp = a.ppt + col * 4;
+            pp[0] = pp[0] + ppt_r;
+            pp[1] = pp[1] + ppt_s;
+            pp[2] = pp[2] + ppt_g;
+            pp[3] = pp[3] + ppt_i;
+        }
+
+        // ============ pass 5: blocks Q + R, M:3584-3686 ============
+#pragma unroll 1
+        for (int j = 0; j < NJ; ++j) {
+            const int k = lane + WAVE * j;
+            if (k >= nz) continue;
+            const int f = flg[j];
+            const double qc1 = (f & F_QC) ? gqc[k] : 0.0, nc1 = (f & F_QC) ? gnc[k] : 0.0;
+            const double qi1 = (f & F_QI) ? gqi[k] : 0.0, ni1 = (f & F_QI) ? gni[k] : 0.0;
+            const double qr1 = (f & F_QR) ? gqr[k] : 0.0, nr1 = (f & F_QR) ? gnr[k] : 0.0;
+            const double qs1 = (f & F_QS) ? gqs[k] : 0.0, qg1 = (f & F_QG) ? gqg[k] : 0.0;
+            const double t1 = gt[k];
+            double tten = L[V_TTEN][k], qcten = L[V_QCTEN][k], ncten = L[V_NCTEN][k];
+            double qiten = L[V_QITEN][k], niten = L[V_NITEN][k];
+            const double qrten = L[V_QRTEN][k], nrten = L[V_NRTEN][k], qsten = L[V_QSTEN][k], qgten = L[V_QGTEN][k];
+            const double temp = L[V_TEMP2][k], rho = L[V_RHO2][k], ocp = L[V_OCP][k], lvap = L[V_LVAP][k];
+
+            if (!iiwarm) {                                   // Q, M:3585-3605
+                const double xri = fmax(0.0, qi1 + qiten * DT);
+                if ((temp > T_0) && (xri > 0.0)) {
+                    qcten = qcten + xri * odt;
+                    ncten = ncten + ni1 * odt;
+                    qiten = qiten - xri * odt;
+                    niten = -ni1 * odt;
+                    tten = tten - lfus * ocp * xri * odt;
+                }
+                const double xrc = fmax(0.0, qc1 + qcten * DT);
+                if ((temp < HGFR) && (xrc > 0.0)) {
+                    const double lfus2 = lsub - lvap;
+                    const double xnc = nc1 + ncten * DT;
+                    qiten = qiten + xrc * odt;
+                    niten = niten + xnc * odt;
+                    qcten = qcten - xrc * odt;
+                    ncten = ncten - xnc * odt;
+                    tten = tten + lfus2 * ocp * xrc * odt;
+                }
+            }
+
+            // R, M:3624-3685
+            a.t[base + k] = t1 + tten * DT;
+            double qc = qc1 + qcten * DT;
+            double ncn = fmax(2. / rho, nc1 + ncten * DT);
+            if (qc <= R1) {
+                qc = 0.0;
+                ncn = 0.0;
+            } else {
+                int nu = int(lround(1000.E6 / (ncn * rho))) + 2;
+                nu = nu < 15 ? nu : 15;
+                double lc = pow(am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] * ncn / qc, obmr);
+                const double xD = (bm_r + nu + 1.) / lc;
+                if (xD < D0c)            lc = c.cce[1][nu - 1] / D0c;
+                else if (xD > D0r * 2.)  lc = c.cce[1][nu - 1] / (D0r * 2.);
+                ncn = fmin(c.ccg[0][nu - 1] * c.ocg2[nu - 1] * qc / am_r * pow(lc, bm_r), Nt_c_max / rho);
+            }
+            a.qc[base + k] = qc;
+            a.nc[base + k] = ncn;
+
+            double qi = qi1 + qiten * DT;
+            double nin = fmax(R2 / rho, ni1 + niten * DT);
+            if (qi <= R1) {
+                qi = 0.0;
+                nin = 0.0;
+            } else {
+                double lami = pow(am_i * c.cig[1] * c.oig1 * nin / qi, obmi);
+                const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
+                if (xDi < 5.E-6)          lami = c.cie[1] / 5.E-6;
+                else if (xDi > 300.E-6)   lami = c.cie[1] / 300.E-6;
+                nin = fmin(c.cig[0] * c.oig2 * qi / am_i * pow(lami, bm_i), 499.e3 / rho);
+            }
+            a.qi[base + k] = qi;
+            a.ni[base + k] = nin;
+
+            double qr = qr1 + qrten * DT;
+            double nrn = fmax(R2 / rho, nr1 + nrten * DT);
+            if (qr <= R1) {
+                qr = 0.0;
+                nrn = 0.0;
+            } else {
+                const double lr = pow(am_r * c.crg[2] * c.org2 * nrn / qr, obmr);
+                double mvd = (3.0 + mu_r + 0.672) / lr;
+                if (mvd > 2.5E-3)           mvd = 2.5E-3;
+                else if (mvd < D0r * 0.75)  mvd = D0r * 0.75;
+                nrn = nr_from_mvd(c, qr, mvd);
+            }
+            a.qr[base + k] = qr;
+            a.nr[base + k] = nrn;
+
+            const double qs = qs1 + qsten * DT;
+            a.qs[base + k] = qs <= R1 ? 0.0 : qs;
+            const double qg = qg1 + qgten * DT;
+            a.qg[base + k] = qg <= R1 ? 0.0 : qg;
+        }
+        __syncthreads();     // LDS is reused by the next column of this block
+    }
+}
+
+const char *column_kernel_name() { return "thompson_column_step"; }
+
+template <int NJ>
+static hipError_t launch_nj(const StepArgs &a, bool rates, int grid, hipStream_t s)
+{
+    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, true>), dim3(grid), dim3(WAVE), 0, s, a);
+    else       hipLaunchKernelGGL((thompson_column_step<NJ, false>), dim3(grid), dim3(WAVE), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_column_step(const StepArgs &a, hipStream_t s)
+{
+    if (a.ncol <= 0) return hipSuccess;
+    if (a.nz < 2 || a.nz > 4 * WAVE) return hipErrorInvalidValue;
+    const int nj = (a.nz + WAVE - 1) / WAVE;
+    const int64_t maxgrid = int64_t(1) << 20;
+    const int grid = int(a.ncol < maxgrid ? a.ncol : maxgrid);
+    const bool rates = a.rates != nullptr;
+    switch (nj) {
+        case 1: return launch_nj<1>(a, rates, grid, s);
+        case 2: return launch_nj<2>(a, rates, grid, s);
+        case 3: return launch_nj<3>(a, rates, grid, s);
+        default: return launch_nj<4>(a, rates, grid, s);
+    }
+}
+
+}  // namespace kidmp

@@ -1,0 +1,239 @@
+"""Host side of the MI355X Thompson-09n column solver.
+
+Mirrors the reference's operator interface for the hot path
+(/root/reference/module_mp_thompson09n.f90, "M:"):
+
+    thompson_init()                 M:374      -> thompson_init(...) / ThompsonMP(...)
+    mp_thompson(qv1d, ..., dt)      M:1156     -> mp_thompson(...) / ThompsonMP.mp_thompson
+    do i=1,nx ... (KiD adapter)     W:54-246   -> ThompsonMP.batch_step (one launch)
+
+Everything numerical happens in kid_amd/libkidmp.so (HIP kernels, C ABI of
+include/kidmp.h).  There is deliberately NO CPU fallback: if the library or a
+gfx950 device is missing, calls raise KidmpError.  torch is used only as the
+owner of device memory and streams.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+STATE_NAMES = ("qv", "qc", "qi", "qr", "qs", "qg", "ni", "nr", "nc", "nwfa", "nifa", "t")   # INOUT, M:1168-1170
+FORCING_NAMES = ("p", "w", "dz")                                                               # IN, M:1171
+RATE_NAMES = (
+    "pri_inu pri_ide prs_ide prs_sde prg_gde pri_wfz prs_scw prg_scw prg_gcw "
+    "pri_ihm pri_rfz prs_iau prs_sci pri_rci pni_inu pni_ihm pni_wfz pni_rfz "
+    "pni_ide pni_iau pni_sci pni_rci prr_sml prr_gml pnr_rcs pnr_rcg pnr_rci "
+    "pnr_sml pnr_gml pnr_rfz prr_wau prr_rcw prv_rev pnr_wau pnr_rev pnr_rcr"
+).split()                                                                                      # M:2967-3119
+NRATES = 36
+MAX_NZ = 256
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class KidmpError(RuntimeError):
+    pass
+
+
+class _Cfg(C.Structure):
+    _fields_ = [("iiwarm", C.c_int32), ("l_sediment", C.c_int32), ("set_Nc", C.c_double),
+                ("device", C.c_int32), ("reserved", C.c_int32)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libkidmp.so")
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+
+def load_library():
+    """dlopen kid_amd/libkidmp.so and declare the C ABI (include/kidmp.h)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise KidmpError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    L = C.CDLL(path)
+    L.kidmp_init.restype = C.c_int
+    L.kidmp_init.argtypes = [C.POINTER(_Cfg), C.POINTER(_vp)]
+    L.kidmp_finalize.restype = None
+    L.kidmp_finalize.argtypes = [_vp]
+    L.kidmp_last_error.restype = C.c_char_p
+    L.kidmp_last_error.argtypes = [_vp]
+    L.kidmp_column_step.restype = C.c_int
+    L.kidmp_column_step.argtypes = [_vp, C.c_int32, C.c_double] + [_dp] * 16
+    L.kidmp_batch_step_host.restype = C.c_int
+    L.kidmp_batch_step_host.argtypes = [_vp, C.c_int64, C.c_int32, C.c_double] + [_dp] * 17
+    L.kidmp_batch_step_device.restype = C.c_int
+    L.kidmp_batch_step_device.argtypes = [_vp, C.c_int64, C.c_int32, C.c_double] + [_vp] * 18 + [_vp]
+    L.kidmp_default_aerosols_device.restype = C.c_int
+    L.kidmp_default_aerosols_device.argtypes = [_vp, C.c_int64] + [_vp] * 6 + [_vp]
+    L.kidmp_reduce_ppt_device.restype = C.c_int
+    L.kidmp_reduce_ppt_device.argtypes = [_vp, C.c_int64, _vp, _vp, _vp]
+    L.kidmp_get_table.restype = C.c_int64
+    L.kidmp_get_table.argtypes = [_vp, C.c_char_p, _dp, C.c_int64]
+    L.kidmp_get_const.restype = C.c_int64
+    L.kidmp_get_const.argtypes = [_vp, C.c_char_p, _dp, C.c_int64]
+    L.kidmp_init_seconds.restype = C.c_double
+    L.kidmp_init_seconds.argtypes = [_vp]
+    L.kidmp_kernel_name.restype = C.c_char_p
+    L.kidmp_kernel_name.argtypes = []
+    _lib = L
+    return L
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+class ThompsonMP:
+    """One context = the module state of module_mp_thompson09n after thompson_init:
+    constants on the host, lookup tables resident in HBM."""
+
+    def __init__(self, iiwarm=False, set_Nc=100.0, l_sediment=True, device=0):
+        self._h = None
+        L = load_library()
+        cfg = _Cfg(int(bool(iiwarm)), int(bool(l_sediment)), float(set_Nc), int(device), 0)
+        h = _vp()
+        rc = L.kidmp_init(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise KidmpError("kidmp_init failed (%d): %s" % (rc, L.kidmp_last_error(None).decode()))
+        self._h = h
+        self.iiwarm = bool(iiwarm)
+        self.device = int(device)
+        self.init_seconds = L.kidmp_init_seconds(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().kidmp_finalize(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise KidmpError("kidmp error %d: %s" % (rc, load_library().kidmp_last_error(self._h).decode()))
+        return rc
+
+    # ---- mp_thompson(qv1d, ..., dt): host arrays, one column (M:1156-1177) ----
+    def mp_thompson(self, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d, t1d,
+                    p1d, w1d, dzq, pptrain=0.0, pptsnow=0.0, pptgraul=0.0, pptice=0.0, dt=10.0):
+        """Arrays (float64, length nz) are updated in place like the Fortran INOUT dummies.
+        Returns the accumulated (pptrain, pptsnow, pptgraul, pptice)."""
+        arrs = [qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d, t1d, p1d, w1d, dzq]
+        nz = len(qv1d)
+        for a in arrs:
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (nz,)):
+                raise KidmpError("mp_thompson: arrays must be contiguous float64 of one length")
+        ppt = np.array([pptrain, pptsnow, pptgraul, pptice], dtype=np.float64)
+        self._check(load_library().kidmp_column_step(self._h, nz, float(dt), *[_np_ptr(a) for a in arrs], _np_ptr(ppt)))
+        return tuple(ppt)
+
+    # ---- batched host entry: numpy [ncol, nz] ----
+    def batch_step_host(self, st, dt, ppt=None, want_rates=False):
+        ncol, nz = st["qv"].shape
+        for k in STATE_NAMES + FORCING_NAMES:
+            a = st[k]
+            if not (a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (ncol, nz)):
+                raise KidmpError("batch_step_host: %s must be contiguous float64 [ncol, nz]" % k)
+        if ppt is None:
+            ppt = np.zeros((ncol, 4))
+        rates = np.zeros((ncol, NRATES, nz)) if want_rates else None
+        self._check(load_library().kidmp_batch_step_host(
+            self._h, ncol, nz, float(dt), *[_np_ptr(st[k]) for k in STATE_NAMES + FORCING_NAMES],
+            _np_ptr(ppt), _np_ptr(rates) if want_rates else None))
+        return ppt, rates
+
+    # ---- batched device entry: torch CUDA tensors [ncol, nz], in place ----
+    def batch_step(self, st, dt, ppt, rates=None, nstep=None, stream=None):
+        """st: dict of float64 CUDA tensors [ncol, nz] (STATE_NAMES + p, dz; w optional).
+        ppt: float64 [ncol, 4], accumulated in place.  Asynchronous on `stream`
+        (default: torch's current stream)."""
+        import torch
+        q = st["qv"]
+        ncol, nz = q.shape
+        for k in STATE_NAMES + ("p", "dz"):
+            a = st[k]
+            if not (a.is_cuda and a.dtype == torch.float64 and a.is_contiguous() and tuple(a.shape) == (ncol, nz)):
+                raise KidmpError("batch_step: %s must be a contiguous float64 CUDA tensor [ncol, nz]" % k)
+        if not (ppt.is_cuda and ppt.dtype == torch.float64 and ppt.is_contiguous() and tuple(ppt.shape) == (ncol, 4)):
+            raise KidmpError("batch_step: ppt must be float64 CUDA [ncol, 4]")
+        if rates is not None and not (rates.is_cuda and rates.dtype == torch.float64 and rates.is_contiguous()
+                                      and tuple(rates.shape) == (ncol, NRATES, nz)):
+            raise KidmpError("batch_step: rates must be float64 CUDA [ncol, 36, nz]")
+        if nstep is not None and not (nstep.is_cuda and nstep.dtype == torch.int32 and nstep.is_contiguous()
+                                      and tuple(nstep.shape) == (ncol, 4)):
+            raise KidmpError("batch_step: nstep must be int32 CUDA [ncol, 4]")
+        s = stream if stream is not None else torch.cuda.current_stream(q.device).cuda_stream
+        w = st.get("w")
+        args = [st[k].data_ptr() for k in STATE_NAMES] + [st["p"].data_ptr(), w.data_ptr() if w is not None else None,
+                                                          st["dz"].data_ptr(), ppt.data_ptr(),
+                                                          rates.data_ptr() if rates is not None else None,
+                                                          nstep.data_ptr() if nstep is not None else None]
+        self._check(load_library().kidmp_batch_step_device(self._h, ncol, nz, float(dt), *args, s))
+
+    def default_aerosols(self, qv, t, p, stream=None):
+        """nc, nwfa, nifa for the inputs the KiD wrapper leaves unset (W:36; formulas M:958-964)."""
+        import torch
+        nc, nwfa, nifa = torch.empty_like(qv), torch.empty_like(qv), torch.empty_like(qv)
+        s = stream if stream is not None else torch.cuda.current_stream(qv.device).cuda_stream
+        self._check(load_library().kidmp_default_aerosols_device(
+            self._h, qv.numel(), qv.data_ptr(), t.data_ptr(), p.data_ptr(), nc.data_ptr(), nwfa.data_ptr(),
+            nifa.data_ptr(), s))
+        return nc, nwfa, nifa
+
+    def reduce_ppt(self, ppt, stream=None):
+        """Domain sums of the surface precipitation on the device (W:248-275 analogue)."""
+        import torch
+        out = torch.empty(4, dtype=torch.float64, device=ppt.device)
+        s = stream if stream is not None else torch.cuda.current_stream(ppt.device).cuda_stream
+        self._check(load_library().kidmp_reduce_ppt_device(self._h, ppt.shape[0], ppt.data_ptr(), out.data_ptr(), s))
+        return out
+
+    # ---- introspection for parity tests ----
+    def table(self, name, shape=None):
+        L = load_library()
+        n = self._check(L.kidmp_get_table(self._h, name.encode(), None, 0))
+        out = np.empty(n)
+        self._check(L.kidmp_get_table(self._h, name.encode(), _np_ptr(out), n))
+        return out.reshape(shape, order="F") if shape else out
+
+    def const(self, name):
+        L = load_library()
+        n = self._check(L.kidmp_get_const(self._h, name.encode(), None, 0))
+        out = np.empty(n)
+        self._check(L.kidmp_get_const(self._h, name.encode(), _np_ptr(out), n))
+        return out
+
+    @staticmethod
+    def kernel_name():
+        return load_library().kidmp_kernel_name().decode()
+
+
+# ---- module-level mirror of the Fortran module procedures ----
+_module_ctx = None
+
+
+def thompson_init(iiwarm=False, set_Nc=100.0, l_sediment=True, device=0):
+    """thompson_init (M:374): builds the module-level context once, like the
+    `micro_unset` guard of the KiD adapter (W:100-103)."""
+    global _module_ctx
+    if _module_ctx is None:
+        _module_ctx = ThompsonMP(iiwarm=iiwarm, set_Nc=set_Nc, l_sediment=l_sediment, device=device)
+    return _module_ctx
+
+
+def mp_thompson(*args, **kw):
+    """mp_thompson (M:1156) on the module-level context."""
+    if _module_ctx is None:
+        raise KidmpError("mp_thompson called before thompson_init")
+    return _module_ctx.mp_thompson(*args, **kw)

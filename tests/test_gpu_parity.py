@@ -1,0 +1,162 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  -m gpu."""
+import numpy as np
+import pytest
+
+import cases
+import kat_cases as kc
+from parity import TOL, max_rel
+
+pytestmark = pytest.mark.gpu
+OUT = ("qv", "qc", "qi", "qr", "qs", "qg", "ni", "nr", "nc", "nwfa", "nifa", "t")
+
+
+def _copy(st):
+    return {k: np.ascontiguousarray(v.copy()) for k, v in st.items()}
+
+
+def _oracle_batch(o, st, dt):
+    ref = _copy(st)
+    ppt = o.batch_step(ref, dt)
+    return ref, ppt
+
+
+def _gpu_batch(m, st, dt, rates=False):
+    got = _copy(st)
+    ppt, r = m.batch_step_host(got, dt, want_rates=rates)
+    return got, ppt, r
+
+
+def _check(got, gppt, ref, rppt, tol=TOL):
+    mx, per = max_rel(got, ref, OUT)
+    pmx = float(np.max(np.abs(gppt - rppt) / np.maximum(np.abs(rppt), 1e-12)))
+    assert mx < tol and pmx < tol, (per, pmx)
+    return mx
+
+
+TABLES = ["tcg_racg", "tmr_racg", "tcr_gacr", "tmg_gacr", "tnr_racg", "tnr_gacr",
+          "tcs_racs1", "tmr_racs1", "tcs_racs2", "tmr_racs2", "tcr_sacr1", "tms_sacr1", "tcr_sacr2", "tms_sacr2",
+          "tnr_racs1", "tnr_racs2", "tnr_sacr1", "tnr_sacr2", "tpi_qcfz", "tni_qcfz", "tpi_qrfz", "tpg_qrfz",
+          "tni_qrfz", "tnr_qrfz", "tps_iaus", "tni_iaus", "tpi_ide", "t_Efrw", "t_Efsw"]
+
+
+@pytest.mark.parametrize("name", TABLES)
+def test_table_matches_oracle(gpu_mixed, oracle_mixed, name):
+    ref = oracle_mixed.table(name)
+    got = gpu_mixed.table(name, ref.shape)
+    scale = np.max(np.abs(ref))
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-30 + 1e-13 * scale)
+    assert np.max(err) < 1e-11, (name, float(np.max(err)))
+
+
+def test_constants_match_oracle(gpu_mixed, oracle_mixed):
+    for n in ("cre", "crg", "cse", "csg", "cge", "cgg", "cie", "cig", "ccg1", "ccg2", "ccg3", "ocg1", "ocg2",
+              "Dr", "dtr", "Ds", "dts", "Dg", "dtg", "Di", "dti", "Dc", "t_Nc", "t1_qr_qc", "t2_qr_qi", "t1_qg_qc",
+              "t2_qr_ev", "t2_qs_sd", "t1_qs_me", "t2_qs_me", "t2_qg_sd", "t1_qg_me", "t2_qg_me", "Sc3", "D0i",
+              "xm0s", "xm0g", "ocms", "ocmg"):
+        np.testing.assert_allclose(gpu_mixed.const(n), oracle_mixed.const(n), rtol=1e-15, atol=0, err_msg=n)
+
+
+def test_interleaved_records_equal_planar_tables(gpu_mixed):
+    racs = gpu_mixed.table("racs_rec").reshape(-1, 10)
+    for i, n in enumerate(["tmr_racs1", "tcr_sacr1", "tmr_racs2", "tcr_sacr2", "tcs_racs1", "tms_sacr1",
+                           "tnr_racs1", "tnr_racs2", "tnr_sacr1", "tnr_sacr2"]):
+        assert np.array_equal(racs[:, i], gpu_mixed.table(n)), n
+    racg = gpu_mixed.table("racg_rec").reshape(-1, 5)
+    for i, n in enumerate(["tmr_racg", "tcr_gacr", "tnr_racg", "tnr_gacr", "tcg_racg"]):
+        assert np.array_equal(racg[:, i], gpu_mixed.table(n)), n
+    q = gpu_mixed.table("qrfz_rec").reshape(-1, 4)
+    for i, n in enumerate(["tpg_qrfz", "tpi_qrfz", "tni_qrfz", "tnr_qrfz"]):
+        assert np.array_equal(q[:, i], gpu_mixed.table(n)), n
+
+
+def test_kat_a_warm_one_step(gpu_warm, oracle_warm):
+    st = cases.replicate(kc.kat_a(False), 3)
+    ref, rppt = _oracle_batch(oracle_warm, st, 10.0)
+    got, gppt, _ = _gpu_batch(gpu_warm, st, 10.0)
+    _check(got, gppt, ref, rppt)
+
+
+def test_kat_a_mixed_one_step(gpu_mixed, oracle_mixed):
+    st = cases.replicate(kc.kat_a(True), 2)
+    ref, rppt = _oracle_batch(oracle_mixed, st, 10.0)
+    got, gppt, _ = _gpu_batch(gpu_mixed, st, 10.0)
+    _check(got, gppt, ref, rppt)
+
+
+def test_edge_cases_one_step(gpu_mixed, oracle_mixed):
+    st = cases.edge_cases()
+    ref, rppt = _oracle_batch(oracle_mixed, st, 10.0)
+    got, gppt, _ = _gpu_batch(gpu_mixed, st, 10.0)
+    _check(got, gppt, ref, rppt)
+    assert got["qc"][1, 5] == 0.0           # no_micro early exit still zeroes sub-R1 species (M:1412)
+
+
+def test_rates_match_oracle(gpu_mixed, oracle_mixed):
+    st = cases.edge_cases()
+    got, gppt, rates = _gpu_batch(gpu_mixed, st, 10.0, rates=True)
+    for c in range(st["qv"].shape[0]):
+        col = {k: st[k][c].copy() for k in st}
+        _, rref, _, _ = oracle_mixed.column_step(col, 10.0, want_rates=True)
+        scale = np.maximum(np.max(np.abs(rref), axis=1, keepdims=True), 1e-300)
+        err = np.abs(rates[c] - rref) / np.maximum(np.abs(rref), 1e-9 * scale)
+        assert np.max(err) < 1e-8, (c, float(np.max(err)), int(np.argmax(np.max(err, axis=1))))
+
+
+def test_kat_c_sedimentation_substeps(gpu_mixed, oracle_mixed):
+    import torch
+    st = cases.replicate(kc.kat_c(), 2)
+    ref = _copy(st)
+    dev = {k: torch.from_numpy(st[k]).cuda() for k in st}
+    ppt = torch.zeros(2, 4, dtype=torch.float64, device="cuda")
+    nstep = torch.zeros(2, 4, dtype=torch.int32, device="cuda")
+    for n in range(3):
+        ppt.zero_()
+        gpu_mixed.batch_step(dev, 10.0, ppt, nstep=nstep)
+        rppt = oracle_mixed.batch_step(ref, 10.0)
+        torch.cuda.synchronize()
+        got = {k: dev[k].cpu().numpy() for k in OUT}
+        _check(got, ppt.cpu().numpy(), ref, rppt, tol=1e-9)
+        assert nstep.cpu().numpy()[0].tolist() == [25 - n, 1, 1, 25 - n]     # KAT-C of SURVEY 9h
+
+
+def test_config3_sample_one_step(gpu_mixed, oracle_mixed):
+    st = cases.config3(ncol=512)
+    ref, rppt = _oracle_batch(oracle_mixed, st, 10.0)
+    got, gppt, _ = _gpu_batch(gpu_mixed, st, 10.0)
+    _check(got, gppt, ref, rppt)
+
+
+def test_config5_sample_one_step(gpu_mixed, oracle_mixed):
+    st = cases.config5(ncol=256)
+    ref, rppt = _oracle_batch(oracle_mixed, st, 10.0)
+    got, gppt, _ = _gpu_batch(gpu_mixed, st, 10.0)
+    _check(got, gppt, ref, rppt)
+
+
+def test_config2_warm_replicated(gpu_warm, oracle_warm):
+    st = cases.config2(oracle_warm, ncol=64)
+    ref, rppt = _oracle_batch(oracle_warm, st, 10.0)
+    got, gppt, _ = _gpu_batch(gpu_warm, st, 10.0)
+    _check(got, gppt, ref, rppt)
+    assert np.array_equal(got["qr"][0], got["qr"][-1])      # replicas are bit-identical
+
+
+def test_multi_step_drift_mixed(gpu_mixed, oracle_mixed):
+    """200 coupled steps (KAT-A mixed): device-resident state vs the oracle chain."""
+    import torch
+    st = cases.replicate(kc.kat_a(True), 1)
+    ref = _copy(st)
+    dev = {k: torch.from_numpy(st[k]).cuda() for k in st}
+    ppt = torch.zeros(1, 4, dtype=torch.float64, device="cuda")
+    for n in range(200):
+        ppt.zero_()
+        gpu_mixed.batch_step(dev, 10.0, ppt)
+        rppt = oracle_mixed.batch_step(ref, 10.0)
+    torch.cuda.synchronize()
+    got = {k: dev[k].cpu().numpy() for k in OUT}
+    mx, per = max_rel(got, ref, OUT)
+    assert mx < 1e-8, per                                   # drift bound; 1-step bound is TOL
+    np.testing.assert_allclose(ppt.cpu().numpy(), rppt, rtol=1e-9, atol=1e-15)
+    # and the survey's known answer for the reference itself (SURVEY 9h KAT-A mixed, 6 digits)
+    assert abs(got["qs"].sum() / 4.26247e-2 - 1) < 2e-6
+    assert abs(float(ppt[0, 0]) / 1.708898e-2 - 1) < 2e-6
