@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- Thompson mp column-steps/s (nz=120) on MI355X.
+
+One "step" = one mp_thompson advance (dt = 10 s) of every column of the batch,
+state resident in HBM.  Default workload = BASELINE.json configs[1]:
+10^4 replicated warm-rain columns (the KiD 1-D warm case at t = 900 s), fp64,
+per GPU (weak scaling: every rank owns its own 10^4 columns, no halo; RCCL only
+for the final precipitation-diagnostics reduction).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     HBM roofline of the column-step kernel: achieved = 19232 B of
+               algorithmic traffic per column-step x columns per
+               launch / average launch duration (HIP events on the launch
+               stream), peak 8 TB/s.
+  cpu_baseline the CPU oracle (a port of the reference, kind "port") timed on
+               this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_FP64 = 19232          # (11 read + 9 written profiles) * 120 * 8 B + 32 B  
+HBM_PEAK = 8.0e12
+NZ = 120
+DT = 10.0
+
+
+def make_workload(name, ncol, model_factory):
+    """Returns (numpy state dict [ncol, nz], iiwarm, description).  Inputs are synthetic; the
+    config-2 column is the config-1 warm column advanced to t=900 s by the HIP path itself."""
+    import cases
+    if name == "config2":
+        m = model_factory(True)
+
+        class _Stepper:                 # same call shape as the test-side oracle stepper
+            def column_step(self, st, dt):
+                import numpy as np
+                ppt = m.mp_thompson(*[st[k] for k in cases.KEYS_ARGS], dt=dt)
+                return np.array(ppt)
+        st = cases.config2(_Stepper(), ncol)
+        return st, True, "config2: %d replicated warm-rain columns (KiD 1-D warm case at t=900 s)" % ncol, m
+    if name == "config3":
+        return (cases.config3(ncol), False,
+                "config3: %d perturbed mixed-phase deep-convection columns" % ncol, model_factory(False))
+    if name == "config5":
+        return (cases.config5(ncol), False,
+                "config5: %d sedimentation-heavy squall-line columns (>=20 CFL substeps)" % ncol, model_factory(False))
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(model, st, iiwarm, budget_s=12.0):
+    """The cpu_baseline leg: the oracle (a CPU port of the reference) on this host's cores on a
+    bounded sample of the same workload, and -- with the same oracle output -- the accuracy figure
+    of BASELINE.json: max relative |dq| of the HIP path after one step from identical inputs
+    (conditioned levels only, see tests/parity.py)."""
+    import numpy as np
+    import torch
+    from oracle.oracle import Oracle
+    from parity import OUT, conditioned_mask, max_rel
+    cores = os.cpu_count() or 1
+    o = Oracle(iiwarm=iiwarm, nthreads=cores)
+    nsamp = min(st["qv"].shape[0], 2000)
+    s0 = {k: np.ascontiguousarray(v[:nsamp].copy()) for k, v in st.items()}
+
+    # accuracy: one step from identical inputs
+    nacc = min(nsamp, 256)
+    sa = {k: np.ascontiguousarray(v[:nacc].copy()) for k, v in s0.items()}
+    ref = {k: v.copy() for k, v in sa.items()}
+    rppt = o.batch_step(ref, DT)
+    mask = conditioned_mask(o, sa, DT, ref)
+    dev = {k: torch.from_numpy(v).cuda() for k, v in sa.items()}
+    ppt = torch.zeros(nacc, 4, dtype=torch.float64, device="cuda")
+    model.batch_step(dev, DT, ppt)
+    torch.cuda.synchronize()
+    got = {k: dev[k].cpu().numpy() for k in OUT}
+    mx, _ = max_rel(got, ref, OUT, mask)
+    pm = float(np.max(np.abs(ppt.cpu().numpy() - rppt) / np.maximum(np.abs(rppt), 1e-12)))
+
+    # timing: all cores, one column per task
+    s = {k: v.copy() for k, v in s0.items()}
+    o.batch_step(s, DT, nthreads=cores)           # page in
+    done, t0 = 0, time.perf_counter()
+    while True:
+        o.batch_step(s, DT, nthreads=cores)
+        done += nsamp
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    s1 = {k: np.ascontiguousarray(v[:200].copy()) for k, v in s0.items()}
+    t1 = time.perf_counter()
+    o.batch_step(s1, DT, nthreads=1)
+    one = 200 / (time.perf_counter() - t1)
+    o.close()
+    return {"value": done / el, "unit": "column-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d columns of the same workload, %d steps, %.1f s, one column per task on %d threads"
+                      % (nsamp, done // nsamp, el, cores),
+            "single_core": one,
+            "max_rel_dq_gpu_vs_cpu": max(mx, pm),
+            "ill_conditioned_levels_excluded": [int((~mask).sum()), int(mask.size)]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
+    ap.add_argument("--ncol", type=int, default=0, help="columns per GPU (default: the config's own size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from kid_amd import STATE_NAMES, ThompsonMP
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))    # "nccl" is RCCL on ROCm
+    ncol = args.ncol or {"config2": 10000, "config3": 100000, "config5": 100000}[args.workload]
+
+    st, iiwarm, desc, model = make_workload(args.workload, ncol, lambda warm: ThompsonMP(iiwarm=warm, device=local))
+    dev = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+    ppt = torch.zeros(ncol, 4, dtype=torch.float64, device="cuda")
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.batch_step(dev, DT, ppt)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()                    # torch's current stream == the stream batch_step launches on
+        model.batch_step(dev, DT, ppt)
+        ev1[i].record()
+    diag = model.reduce_ppt(ppt)           # domain sums of surface precipitation (W:248-275 analogue)
+    if world > 1:
+        dist.all_reduce(diag)              # the only collective: final diagnostics reduction
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+
+    if rank == 0:
+        total_cols = ncol * world
+        value = total_cols * args.steps / elapsed
+        achieved = ALGO_BYTES_FP64 * ncol / (kern_ms * 1e-3)
+        out = {
+            "metric": "thompson_mp_column_steps_per_sec", "value": value, "unit": "column-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc + ", nz=120, dt=10 s, fp64", "ncol_per_gpu": ncol, "nz": NZ, "dt": DT,
+                       "parallelism": "columns sharded over ranks, no halo; one RCCL all-reduce of 4 precipitation sums"},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel": ThompsonMP.kernel_name(), "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_column_step": ALGO_BYTES_FP64,
+                         "note": "fp64 transcendental-bound path (SURVEY 8d): the HBM fraction is reported as "
+                                 "mandated; see DESIGN.md for the VALU-side accounting"},
+            "precip_domain_sums": [float(x) for x in diag.cpu().tolist()],
+            "init_seconds": model.init_seconds,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, st, iiwarm)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

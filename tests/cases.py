@@ -11,6 +11,7 @@ import kat_cases as kc
 NZ = 120
 SEED = 20241008
 KEYS = ("qv", "qc", "qi", "qr", "qs", "qg", "ni", "nr", "nc", "nwfa", "nifa", "t", "p", "w", "dz")
+KEYS_ARGS = KEYS   # positional order of mp_thompson's array dummies (M:1156-1157)
 
 
 def _defaults(st, set_Nc=100.0):
@@ -25,9 +26,9 @@ def replicate(col, ncol):
     return {k: np.ascontiguousarray(np.broadcast_to(col[k], (ncol, col[k].shape[0])).copy()) for k in KEYS}
 
 
-def warm_column_t900(oracle_warm, nsteps=90):
-    """config 2 base column: the config-1 (KAT-B like) warm column advanced to t=900 s
-    by the oracle (cloud + rain present)."""
+def warm_column_t900(stepper, nsteps=90):
+    """config 2 base column: the config-1 (KAT-B like) warm column advanced to t=900 s by
+    `stepper.column_step(st, dt)` -- the oracle in tests, the HIP path in bench.py."""
     c = kc.kat_b()
     nz = c["nz"]
     p = c["p0"] * c["exner"] ** (1.0 / c["r_on_cp"])
@@ -37,12 +38,12 @@ def warm_column_t900(oracle_warm, nsteps=90):
     _defaults(st)
     st = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in st.items()}
     for _ in range(nsteps):
-        oracle_warm.column_step(st, 10.0)
+        stepper.column_step(st, 10.0)
     return st
 
 
-def config2(oracle_warm, ncol=10000):
-    return replicate(warm_column_t900(oracle_warm), ncol)
+def config2(stepper, ncol=10000):
+    return replicate(warm_column_t900(stepper), ncol)
 
 
 def _perturb(base, ncol, rng, sigma=0.3, dT=1.5):

@@ -4,10 +4,9 @@ import pytest
 
 import cases
 import kat_cases as kc
-from parity import TOL, max_rel
+from parity import OUT, TOL, conditioned_mask, max_rel
 
 pytestmark = pytest.mark.gpu
-OUT = ("qv", "qc", "qi", "qr", "qs", "qg", "ni", "nr", "nc", "nwfa", "nifa", "t")
 
 
 def _copy(st):
@@ -26,10 +25,12 @@ def _gpu_batch(m, st, dt, rates=False):
     return got, ppt, r
 
 
-def _check(got, gppt, ref, rppt, tol=TOL):
-    mx, per = max_rel(got, ref, OUT)
+def _check(got, gppt, ref, rppt, tol=TOL, mask=None, max_excluded=0):
+    mx, per = max_rel(got, ref, OUT, mask)
     pmx = float(np.max(np.abs(gppt - rppt) / np.maximum(np.abs(rppt), 1e-12)))
     assert mx < tol and pmx < tol, (per, pmx)
+    if mask is not None:
+        assert int((~mask).sum()) <= max_excluded, int((~mask).sum())
     return mx
 
 
@@ -87,7 +88,8 @@ def test_edge_cases_one_step(gpu_mixed, oracle_mixed):
     st = cases.edge_cases()
     ref, rppt = _oracle_batch(oracle_mixed, st, 10.0)
     got, gppt, _ = _gpu_batch(gpu_mixed, st, 10.0)
-    _check(got, gppt, ref, rppt)
+    mask = conditioned_mask(oracle_mixed, st, 10.0, ref)     # excludes the M:3596 residue branch (see parity.py)
+    _check(got, gppt, ref, rppt, mask=mask, max_excluded=4)
     assert got["qc"][1, 5] == 0.0           # no_micro early exit still zeroes sub-R1 species (M:1412)
 
 
@@ -123,14 +125,17 @@ def test_config3_sample_one_step(gpu_mixed, oracle_mixed):
     st = cases.config3(ncol=512)
     ref, rppt = _oracle_batch(oracle_mixed, st, 10.0)
     got, gppt, _ = _gpu_batch(gpu_mixed, st, 10.0)
-    _check(got, gppt, ref, rppt)
+    # this profile keeps liquid cloud up to 228 K, so ~1.4 % of its levels sit on the M:3596 residue branch
+    mask = conditioned_mask(oracle_mixed, st, 10.0, ref)
+    _check(got, gppt, ref, rppt, mask=mask, max_excluded=int(3e-2 * mask.size))
 
 
 def test_config5_sample_one_step(gpu_mixed, oracle_mixed):
     st = cases.config5(ncol=256)
     ref, rppt = _oracle_batch(oracle_mixed, st, 10.0)
     got, gppt, _ = _gpu_batch(gpu_mixed, st, 10.0)
-    _check(got, gppt, ref, rppt)
+    mask = conditioned_mask(oracle_mixed, st, 10.0, ref)
+    _check(got, gppt, ref, rppt, mask=mask, max_excluded=int(2e-3 * mask.size))
 
 
 def test_config2_warm_replicated(gpu_warm, oracle_warm):
