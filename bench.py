@@ -31,26 +31,18 @@ NZ = 120
 DT = 10.0
 
 
-def make_workload(name, ncol, model_factory):
-    """Returns (numpy state dict [ncol, nz], iiwarm, description).  Inputs are synthetic; the
-    config-2 column is the config-1 warm column advanced to t=900 s by the HIP path itself."""
+def make_workload(name, ncol):
+    """Returns (numpy state dict [ncol, nz], iiwarm, description).  Synthetic inputs only
+    (tests/cases.py; the config-2 base column is the committed fixture tests/golden/)."""
     import cases
     if name == "config2":
-        m = model_factory(True)
-
-        class _Stepper:                 # same call shape as the test-side oracle stepper
-            def column_step(self, st, dt):
-                import numpy as np
-                ppt = m.mp_thompson(*[st[k] for k in cases.KEYS_ARGS], dt=dt)
-                return np.array(ppt)
-        st = cases.config2(_Stepper(), ncol)
-        return st, True, "config2: %d replicated warm-rain columns (KiD 1-D warm case at t=900 s)" % ncol, m
+        return (cases.config2(ncol), True,
+                "config2: %d replicated warm-rain columns (KiD 1-D warm case at t=900 s)" % ncol)
     if name == "config3":
-        return (cases.config3(ncol), False,
-                "config3: %d perturbed mixed-phase deep-convection columns" % ncol, model_factory(False))
+        return cases.config3(ncol), False, "config3: %d perturbed mixed-phase deep-convection columns" % ncol
     if name == "config5":
         return (cases.config5(ncol), False,
-                "config5: %d sedimentation-heavy squall-line columns (>=20 CFL substeps)" % ncol, model_factory(False))
+                "config5: %d sedimentation-heavy squall-line columns (>=20 CFL substeps)" % ncol)
     raise SystemExit("unknown workload " + name)
 
 
@@ -130,7 +122,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))    # "nccl" is RCCL on ROCm
     ncol = args.ncol or {"config2": 10000, "config3": 100000, "config5": 100000}[args.workload]
 
-    st, iiwarm, desc, model = make_workload(args.workload, ncol, lambda warm: ThompsonMP(iiwarm=warm, device=local))
+    st, iiwarm, desc = make_workload(args.workload, ncol)
+    model = ThompsonMP(iiwarm=iiwarm, device=local)
     dev = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
     ppt = torch.zeros(ncol, 4, dtype=torch.float64, device="cuda")
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]

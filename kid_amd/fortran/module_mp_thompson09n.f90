@@ -1,0 +1,166 @@
+!
+! module_mp_thompson09n -- drop-in replacement for the reference module of the
+! same name (/root/reference/module_mp_thompson09n.f90, "M:").  It keeps the two
+! procedures the KiD adapter calls, with the reference's dummy lists:
+!
+!     thompson_init()                                   M:374
+!     mp_thompson(qv1d, ..., kts, kte, dt, ii, jj)      M:1156-1177
+!
+! and adds the batched form of the adapter's `do i=1,nx` loop (W:54-246):
+!
+!     mp_thompson_batch(ncol, nz, dt, qv, ..., ppt)
+!
+! Bodies are ISO_C_BINDING calls into libkidmp.so (include/kidmp.h), where the
+! column physics runs as hand-written HIP kernels on an MI355X.  State arrays
+! are copied to REAL(c_double) temporaries, so the module works whether KiD is
+! compiled with 4-byte or 8-byte default REAL (the computation is fp64).
+!
+! Like the reference it takes its switches from KiD's own modules:
+! iiwarm, set_Nc (namelists, M:22) and l_sediment (switches, M:20).
+!
+module module_mp_thompson09n
+
+  use iso_c_binding
+  use switches, only: l_sediment
+  use namelists, only: iiwarm, set_Nc
+
+  implicit none
+  private
+
+  public :: thompson_init, mp_thompson, mp_thompson_batch, thompson_finalize
+  logical, public :: is_aerosol_aware = .false.          ! M:28 (only .false. is supported)
+
+  type, bind(C) :: kidmp_cfg
+     integer(c_int32_t) :: iiwarm
+     integer(c_int32_t) :: l_sediment
+     real(c_double)     :: set_Nc
+     integer(c_int32_t) :: device
+     integer(c_int32_t) :: reserved
+  end type kidmp_cfg
+
+  type(c_ptr), save :: ctx = c_null_ptr
+
+  interface
+     integer(c_int) function kidmp_init(cfg, ctx_out) bind(C, name='kidmp_init')
+       import :: c_int, c_ptr, kidmp_cfg
+       type(kidmp_cfg), intent(in) :: cfg
+       type(c_ptr), intent(out) :: ctx_out
+     end function kidmp_init
+     subroutine kidmp_finalize(ctx) bind(C, name='kidmp_finalize')
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+     end subroutine kidmp_finalize
+     function kidmp_last_error(ctx) result(msg) bind(C, name='kidmp_last_error')
+       import :: c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr) :: msg
+     end function kidmp_last_error
+     integer(c_int) function kidmp_batch_step_host(ctx, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, &
+          nc, nwfa, nifa, t, p, w, dz, ppt, rates) bind(C, name='kidmp_batch_step_host')
+       import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), value :: ncol
+       integer(c_int32_t), value :: nz
+       real(c_double), value :: dt
+       real(c_double), intent(inout) :: qv(*), qc(*), qi(*), qr(*), qs(*), qg(*), ni(*), nr(*), &
+            nc(*), nwfa(*), nifa(*), t(*), ppt(*)
+       real(c_double), intent(in) :: p(*), w(*), dz(*)
+       type(c_ptr), value :: rates
+     end function kidmp_batch_step_host
+  end interface
+
+contains
+
+  subroutine stop_on_error(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(*), intent(in) :: where
+    character(kind=c_char), pointer :: cmsg(:)
+    type(c_ptr) :: p
+    integer :: n
+    if (rc == 0) return
+    p = kidmp_last_error(ctx)
+    write(*,'(a,a,a,i0)') ' module_mp_thompson09n: ', where, ' failed, kidmp code ', rc
+    if (c_associated(p)) then
+       call c_f_pointer(p, cmsg, [512])
+       n = 1
+       do while (n < 512 .and. cmsg(n) /= c_null_char)
+          n = n + 1
+       end do
+       write(*,'(1x,512a1)') cmsg(1:n-1)
+    end if
+    stop 1      ! the reference aborts on init failure too (Fortran runtime error at M:3718)
+  end subroutine stop_on_error
+
+  ! thompson_init, M:374-797: constants on the host, lookup tables built on the GPU.
+  subroutine thompson_init
+    type(kidmp_cfg) :: cfg
+    integer(c_int) :: rc
+    if (c_associated(ctx)) return                         ! micro_init guard, M:384-389
+    if (is_aerosol_aware) then
+       write(*,*) 'module_mp_thompson09n: is_aerosol_aware=.true. is not supported by the MI355X build'
+       stop 1
+    end if
+    cfg%iiwarm = merge(1_c_int32_t, 0_c_int32_t, iiwarm)
+    cfg%l_sediment = merge(1_c_int32_t, 0_c_int32_t, l_sediment)
+    cfg%set_Nc = real(set_Nc, c_double)
+    cfg%device = 0
+    cfg%reserved = 0
+    rc = kidmp_init(cfg, ctx)
+    call stop_on_error(rc, 'thompson_init')
+  end subroutine thompson_init
+
+  subroutine thompson_finalize
+    if (c_associated(ctx)) call kidmp_finalize(ctx)
+    ctx = c_null_ptr
+  end subroutine thompson_finalize
+
+  ! mp_thompson, M:1156-1177: one column, reference dummy list.
+  subroutine mp_thompson (qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, &
+       nr1d, nc1d, nwfa1d, nifa1d, t1d, p1d, w1d, dzq, &
+       pptrain, pptsnow, pptgraul, pptice, &
+       kts, kte, dt, ii, jj)
+    integer, intent(in) :: kts, kte, ii, jj
+    real, dimension(kts:kte), intent(inout) :: qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, &
+         nr1d, nc1d, nwfa1d, nifa1d, t1d
+    real, dimension(kts:kte), intent(in) :: p1d, w1d, dzq
+    real, intent(inout) :: pptrain, pptsnow, pptgraul, pptice
+    real, intent(in) :: dt
+    real :: ppt(4,1)
+    integer :: nz
+    nz = kte - kts + 1
+    ppt(:,1) = (/ pptrain, pptsnow, pptgraul, pptice /)
+    call mp_thompson_batch(1, nz, dt, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, &
+         nifa1d, t1d, p1d, w1d, dzq, ppt)
+    pptrain = ppt(1,1); pptsnow = ppt(2,1); pptgraul = ppt(3,1); pptice = ppt(4,1)
+    if (.false.) print *, ii, jj          ! ii, jj are debug-only in the reference (M:1269-1274)
+  end subroutine mp_thompson
+
+  ! ncol columns in one launch.  Arrays are (nz, ncol), k fastest -- KiD's own
+  ! storage order -- and ppt is (4, ncol) = rain, snow, graupel, ice, accumulated.
+  subroutine mp_thompson_batch(ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt)
+    integer, intent(in) :: ncol, nz
+    real, intent(in) :: dt
+    real, dimension(nz,ncol), intent(inout) :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t
+    real, dimension(nz,ncol), intent(in) :: p, w, dz
+    real, dimension(4,ncol), intent(inout) :: ppt
+    real(c_double), allocatable :: s(:,:,:), f(:,:,:), pp(:,:)
+    integer(c_int) :: rc
+    if (.not. c_associated(ctx)) call thompson_init
+    allocate(s(nz,ncol,12), f(nz,ncol,3), pp(4,ncol))
+    s(:,:,1) = qv;  s(:,:,2) = qc;  s(:,:,3) = qi;   s(:,:,4) = qr
+    s(:,:,5) = qs;  s(:,:,6) = qg;  s(:,:,7) = ni;   s(:,:,8) = nr
+    s(:,:,9) = nc;  s(:,:,10) = nwfa; s(:,:,11) = nifa; s(:,:,12) = t
+    f(:,:,1) = p;   f(:,:,2) = w;   f(:,:,3) = dz
+    pp = ppt
+    rc = kidmp_batch_step_host(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_double), &
+         s(:,:,1), s(:,:,2), s(:,:,3), s(:,:,4), s(:,:,5), s(:,:,6), s(:,:,7), s(:,:,8), &
+         s(:,:,9), s(:,:,10), s(:,:,11), s(:,:,12), f(:,:,1), f(:,:,2), f(:,:,3), pp, c_null_ptr)
+    call stop_on_error(rc, 'mp_thompson')
+    qv = s(:,:,1);  qc = s(:,:,2);  qi = s(:,:,3);   qr = s(:,:,4)
+    qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7);   nr = s(:,:,8)
+    nc = s(:,:,9);  nwfa = s(:,:,10); nifa = s(:,:,11); t = s(:,:,12)
+    ppt = pp
+    deallocate(s, f, pp)
+  end subroutine mp_thompson_batch
+
+end module module_mp_thompson09n

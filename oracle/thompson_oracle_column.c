@@ -112,6 +112,19 @@ int th_oracle_mp_thompson(const th_oracle *o,
                           const double *dzq, double ppt[4],
                           int nz, double dt, double *rates, int *nstep_out)
 {
+    return th_oracle_mp_thompson_ex(o, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d,
+                                    t1d, p1d, w1d, dzq, ppt, nz, dt, rates, nstep_out, NULL);
+}
+
+int th_oracle_mp_thompson_ex(const th_oracle *o,
+                             double *qv1d, double *qc1d, double *qi1d,
+                             double *qr1d, double *qs1d, double *qg1d,
+                             double *ni1d, double *nr1d, double *nc1d,
+                             double *nwfa1d, double *nifa1d, double *t1d,
+                             const double *p1d, const double *w1d,
+                             const double *dzq, double ppt[4],
+                             int nz, double dt, double *rates, int *nstep_out, int *illcond)
+{
     (void)w1d;   /* only read by activ_ncloud (aerosol-aware, M:2797) */
     const int kts = 0, kte = nz - 1;
     const size_t NA = 160;
@@ -193,6 +206,7 @@ int th_oracle_mp_thompson(const th_oracle *o,
     /* M:1282-1381: all arrays are zero from calloc */
     if (rates) memset(rates, 0, sizeof(double) * TH_ORACLE_NRATES * (size_t)nz);
     if (nstep_out) { nstep_out[0] = nstep_out[1] = nstep_out[2] = nstep_out[3] = 0; }
+    if (illcond) memset(illcond, 0, sizeof(int) * (size_t)nz);
 
     /* ---- B: put column of data into local arrays, M:1387-1493 ---- */
     for (k = kts; k <= kte; k++) {
@@ -1456,6 +1470,14 @@ int th_oracle_mp_thompson(const th_oracle *o,
     if (!iiwarm) {
         for (k = kts; k <= kte; k++) {
             xri = MAXD(0.0, qi1d[k] + qiten[k] * DT);
+            if (illcond) {
+                /* conditioning diagnostics (oracle only): the two `> 0.0` tests of this block are
+                 * taken on cancellation residues when the species was removed completely */
+                double sc = MAXD(fabs(qi1d[k]), fabs(qiten[k] * DT));
+                if (temp[k] > T_0 && sc > 0. && fabs(qi1d[k] + qiten[k] * DT) <= 1e-9 * sc) illcond[k] |= 1;
+                sc = MAXD(fabs(qc1d[k]), fabs(qcten[k] * DT));
+                if (temp[k] < HGFR && sc > 0. && fabs(qc1d[k] + qcten[k] * DT) <= 1e-9 * sc) illcond[k] |= 2;
+            }
             if ((temp[k] > T_0) && (xri > 0.0)) {
                 qcten[k] = qcten[k] + xri * odt;
                 ncten[k] = ncten[k] + ni1d[k] * odt;
@@ -1559,7 +1581,7 @@ void th_oracle_default_aerosols(const th_oracle *o, int nz,
 typedef struct {
     const th_oracle *o; long c0, c1; int nz; double dt;
     double *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;
-    const double *p, *w, *dz; double *ppt;
+    const double *p, *w, *dz; double *ppt; int *illcond;
 } batch_job;
 
 static void *batch_worker(void *arg)
@@ -1568,11 +1590,11 @@ static void *batch_worker(void *arg)
     const size_t nz = (size_t)b->nz;
     for (long c = b->c0; c < b->c1; c++) {
         size_t off = (size_t)c * nz;
-        th_oracle_mp_thompson(b->o, b->qv + off, b->qc + off, b->qi + off, b->qr + off,
-                              b->qs + off, b->qg + off, b->ni + off, b->nr + off,
-                              b->nc + off, b->nwfa + off, b->nifa + off, b->t + off,
-                              b->p + off, b->w + off, b->dz + off, b->ppt + 4 * (size_t)c,
-                              b->nz, b->dt, NULL, NULL);
+        th_oracle_mp_thompson_ex(b->o, b->qv + off, b->qc + off, b->qi + off, b->qr + off,
+                                 b->qs + off, b->qg + off, b->ni + off, b->nr + off,
+                                 b->nc + off, b->nwfa + off, b->nifa + off, b->t + off,
+                                 b->p + off, b->w + off, b->dz + off, b->ppt + 4 * (size_t)c,
+                                 b->nz, b->dt, NULL, NULL, b->illcond ? b->illcond + off : NULL);
     }
     return NULL;
 }
@@ -1584,13 +1606,24 @@ int th_oracle_batch(const th_oracle *o, long ncol, int nz, double dt,
                     const double *p, const double *w, const double *dz,
                     double *ppt, int nthreads)
 {
+    return th_oracle_batch_ex(o, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt,
+                              nthreads, NULL);
+}
+
+int th_oracle_batch_ex(const th_oracle *o, long ncol, int nz, double dt,
+                       double *qv, double *qc, double *qi, double *qr,
+                       double *qs, double *qg, double *ni, double *nr,
+                       double *nc, double *nwfa, double *nifa, double *t,
+                       const double *p, const double *w, const double *dz,
+                       double *ppt, int nthreads, int *illcond)
+{
     if (nthreads < 1) nthreads = 1;
     if (nthreads > ncol) nthreads = (int)(ncol > 0 ? ncol : 1);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
     batch_job *jb = (batch_job *)malloc(sizeof(batch_job) * nthreads);
     for (int i = 0; i < nthreads; i++) {
         batch_job b = { o, ncol * i / nthreads, ncol * (i + 1) / nthreads, nz, dt,
-                        qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt };
+                        qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt, illcond };
         jb[i] = b;
         if (nthreads == 1) batch_worker(&jb[i]);
         else pthread_create(&th[i], NULL, batch_worker, &jb[i]);

@@ -26,9 +26,8 @@ def replicate(col, ncol):
     return {k: np.ascontiguousarray(np.broadcast_to(col[k], (ncol, col[k].shape[0])).copy()) for k in KEYS}
 
 
-def warm_column_t900(stepper, nsteps=90):
-    """config 2 base column: the config-1 (KAT-B like) warm column advanced to t=900 s by
-    `stepper.column_step(st, dt)` -- the oracle in tests, the HIP path in bench.py."""
+def warm_column_t0():
+    """config 1 initial column: the KAT-B sounding of SURVEY 9h (dz=25 m, warm, static cloud/rain layer)."""
     c = kc.kat_b()
     nz = c["nz"]
     p = c["p0"] * c["exner"] ** (1.0 / c["r_on_cp"])
@@ -36,14 +35,18 @@ def warm_column_t900(stepper, nsteps=90):
               nr=c["hydro"][1, 1, 0].copy(), qi=np.zeros(nz), ni=np.zeros(nz), qs=np.zeros(nz), qg=np.zeros(nz),
               t=c["theta"] * c["exner"], p=p, w=np.zeros(nz), dz=c["dz"].copy())
     _defaults(st)
-    st = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in st.items()}
-    for _ in range(nsteps):
-        stepper.column_step(st, 10.0)
-    return st
+    return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in st.items()}
 
 
-def config2(stepper, ncol=10000):
-    return replicate(warm_column_t900(stepper), ncol)
+def warm_column_t900():
+    """config 2 base column (cloud + rain present): committed fixture, see golden/make_config2_column.py."""
+    import os
+    f = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config2_column_t900.npz"))
+    return {k: np.ascontiguousarray(f[k]) for k in KEYS}
+
+
+def config2(ncol=10000):
+    return replicate(warm_column_t900(), ncol)
 
 
 def _perturb(base, ncol, rng, sigma=0.3, dT=1.5):

@@ -34,12 +34,16 @@ def max_rel(got, ref, keys=OUT, mask=None):
     return max(per.values()), per
 
 
-def conditioned_mask(oracle, st, dt, ref, nperturb=4, thresh=1e-7):
-    """True where the reference map is well conditioned at this input:
-    ulp-sized input perturbations move no output of the level by more than
-    `thresh` (a well-conditioned level moves by ~1e-13)."""
+def conditioned_mask(oracle, st, dt, ref, nperturb=2, thresh=1e-7):
+    """True where the reference map is well conditioned at this input.  Two detectors:
+    (1) the oracle's own flags for the two `> 0.` tests of M:3587/M:3596 taken on a
+        cancellation residue (deterministic);
+    (2) generic: ulp-sized input perturbations move no output of the level by more than
+        `thresh` (a well-conditioned level moves by ~1e-13)."""
     ncol, nz = st["qv"].shape
-    ok = np.ones((ncol, nz), dtype=bool)
+    probe = {k: np.ascontiguousarray(v.copy()) for k, v in st.items()}
+    _, flags = oracle.batch_step(probe, dt, want_illcond=True)
+    ok = flags == 0
     fac = [(1 + 2 * _EPS, 1 - 2 * _EPS), (1 - 2 * _EPS, 1 + 2 * _EPS), (1 + 4 * _EPS, 1 + 2 * _EPS),
            (1 - 4 * _EPS, 1 - 2 * _EPS), (1 + 6 * _EPS, 1 - 4 * _EPS), (1 - 6 * _EPS, 1 + 4 * _EPS)]
     for ft, fq in fac[:nperturb]:

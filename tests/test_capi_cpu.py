@@ -1,0 +1,67 @@
+"""The C-ABI library: it loads, exports every symbol include/kidmp.h declares, and refuses
+loudly (no CPU fallback) when there is no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "kidmp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(kidmp_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = _declared_symbols()
+    for s in ("kidmp_init", "kidmp_finalize", "kidmp_column_step", "kidmp_batch_step_host",
+              "kidmp_batch_step_device", "kidmp_default_aerosols_device", "kidmp_reduce_ppt_device",
+              "kidmp_get_table", "kidmp_get_const", "kidmp_last_error"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from kid_amd import lib_path
+    lib = ctypes.CDLL(lib_path())
+    for s in _declared_symbols():
+        assert hasattr(lib, s), s
+
+
+def test_no_signature_uses_torch_or_cxx_types():
+    hdr = open(os.path.join(ROOT, "include", "kidmp.h")).read()
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # declarations only, comments stripped
+    assert "torch" not in code and "std::" not in code and "hipStream_t" not in code and "#include <hip" not in code
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from kid_amd import KidmpError, ThompsonMP
+    with pytest.raises(KidmpError) as e:
+        ThompsonMP(iiwarm=True)
+    assert "no HIP device" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """kid_amd/ must not reference oracle/ in any form (the oracle is test infrastructure)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "kid_amd")):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".f90", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "th_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_fortran_shim_binds_the_c_abi():
+    src = open(os.path.join(ROOT, "kid_amd", "fortran", "module_mp_thompson09n.f90")).read()
+    for s in ("kidmp_init", "kidmp_finalize", "kidmp_batch_step_host", "kidmp_last_error"):
+        assert "name='%s'" % s in src
+    # the reference's dummy list, M:1156-1162
+    assert re.search(r"subroutine mp_thompson \(qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, &\s*"
+                     r"nr1d, nc1d, nwfa1d, nifa1d, t1d, p1d, w1d, dzq, &\s*"
+                     r"pptrain, pptsnow, pptgraul, pptice, &\s*kts, kte, dt, ii, jj\)", src)
