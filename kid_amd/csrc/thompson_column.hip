@@ -114,6 +114,25 @@ __device__ inline void shift_from_above(const double (&s)[NJ], double (&up)[NJ])
     }
 }
 
+
+// ---- powers with exponents fixed by the scheme's PARAMETERs ----
+// The reference writes x**cre(n) etc. with run-time exponents, but every one of
+// them is a compile-time constant of the scheme (M:452-553 from bm_*, bv_*, mu_*).
+// Where that constant is an integer, a half-integer, 1/3, 1/4 or 1/6 the power is
+// taken with multiplies, sqrt and cbrt (each correctly rounded or <= 1 ulp), which
+// agrees with libm pow to 1-3 ulp at a fraction of its ~300 fp64 instructions.
+static_assert(bm_r == 3.0 && bm_i == 3.0 && bm_g == 3.0 && bm_s == 2.0, "mass exponents");
+static_assert(mu_r == 0.0 && mu_g == 0.0 && mu_i == 0.0 && bv_r == 1.0 && bv_i == 1.0, "PSD/fallspeed exponents");
+__device__ inline double cube(double x) { return x * x * x; }                      // **bm_r, **bm_i, **bm_g
+__device__ inline double pw4(double x) { const double s = x * x; return s * s; }   // **cre(1), cre(3), cre(9), cge(1)
+__device__ inline double pw5(double x) { const double s = x * x; return s * s * x; }           // **cre(6)
+__device__ inline double pw7(double x) { const double s = x * x; return s * s * s * x; }       // **cre(8)
+__device__ inline double pw2h(double x) { return x * x * sqrt(x); }                // **cre(12) = 2.5
+__device__ inline double pw3h(double x) { return x * x * x * sqrt(x); }            // **cre(7)  = 3.5
+__device__ inline double root3(double x) { return cbrt(x); }                       // **obmr, **obmi, **obmg
+__device__ inline double root4(double x) { return sqrt(sqrt(x)); }                 // **oge1 = 1/(bm_g+1)
+__device__ inline double root6(double x) { return sqrt(cbrt(x)); }                 // **(1./6.), M:1701
+
 // ---------------- scalar helpers ----------------
 // 10.**n as flang lowers real**integer (compiler-rt __powidf2), M:1766 etc.
 __device__ inline double pow10i(int b)
@@ -176,7 +195,7 @@ __device__ inline double fit(const double *s, double tc, double x)
 }
 __device__ inline double snow_moment(const Consts &c, double tc0, double order, double smo2)
 {
-    const double a_ = pow(10.0, fit(c.sa, tc0, order));
+    const double a_ = exp10(fit(c.sa, tc0, order));
     const double b_ = fit(c.sb, tc0, order);
     return a_ * pow(smo2, b_);
 }
@@ -187,7 +206,7 @@ __device__ inline double graupel_N0(bool use_rain, double mvd_r, double rg)
     const double xslw1 = use_rain ? 4.01 + log10(mvd_r) : 0.01;
     const double ygra1 = 4.31 + log10(fmax(5.E-5, rg));
     const double zans1 = 3.1 + (100. / (300. * xslw1 * ygra1 / (10. / xslw1 + 1. + 0.25 * ygra1) + 30. + 10. * ygra1));
-    const double N0 = pow(10., zans1);
+    const double N0 = exp10(zans1);
     return fmax(gonv_min, fmin(N0, gonv_max));
 }
 
@@ -195,20 +214,22 @@ __device__ inline double graupel_N0(bool use_rain, double mvd_r, double rg)
 __device__ inline double nr_from_mvd(const Consts &c, double rr, double mvd)
 {
     const double lamr = (3.0 + mu_r + 0.672) / mvd;
-    return c.crg[1] * c.org3 * rr * pow(lamr, bm_r) / am_r;
+    return c.crg[1] * c.org3 * rr * cube(lamr) / am_r;
 }
 
-// LDS slots ([slot][level]); S0 = after block C, S1 = after block J, S2 = after block N
+// LDS slots ([slot][level]).  S0 = after block C, S1 = after block J, S2 = after block N.
+// A level's slots are only ever touched by the lane that owns the level, and each
+// phase writes its results after it has read its inputs, so later phases reuse slots.
 enum Slot {
-    // S0
-    V_TEMP = 0, V_QV, V_RHO, V_RC, V_RI, V_RR, V_RS, V_RG, V_NI, V_NR, V_QVS, V_QVSI, V_SSATW, V_SSATI,
-    V_DIFFU, V_N0X,
-    // S1/S2 tendencies reuse the first slots of S0 (same lane owns the level)
+    // S0 (written in pass 0, read in pass 1)
+    V_TEMP = 0, V_QV, V_RHO, V_RC, V_RI, V_RR, V_RS, V_RG, V_NI, V_NR, V_QVSI, V_SSATW, V_SSATI, V_DIFFU, V_N0X,
+    // S1 (written at the end of pass 1)
     V_TTEN = 0, V_QVTEN, V_QCTEN, V_NCTEN, V_QITEN, V_NITEN, V_QRTEN, V_NRTEN, V_QSTEN, V_QGTEN,
     V_PRRGML, V_BOOST,
-    // S2 extras
-    V_TEMP2 = 12, V_RHO2, V_RI2, V_NI2, V_RR2, V_NR2, V_RS2, V_RG2, V_XDS, V_OCP, V_LVAP, V_N0X2,
-    NSLOT = 24
+    // S2 (written at the end of pass 2): keeps the tendencies, drops qvten / prr_gml
+    V_OCP = V_QVTEN, V_LVAP = V_PRRGML,
+    V_TEMP2 = 12, V_RHO2, V_RI2, V_NI2, V_RR2, V_NR2, V_RS2, V_RG2, V_XDS,
+    NSLOT = 21
 };
 
 enum Flag { F_QC = 1, F_QI = 2, F_QR = 4, F_QS = 8, F_QG = 16 };
@@ -216,10 +237,11 @@ enum Flag { F_QC = 1, F_QI = 2, F_QR = 4, F_QS = 8, F_QG = 16 };
 }  // namespace
 
 template <int NJ, bool RATES>
-__global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
+__global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a)
 {
-    constexpr int NL = NJ * WAVE;
-    __shared__ double L[NSLOT][NL];
+    extern __shared__ double Ldyn[];                 // [NSLOT][lstride], lstride = nz rounded up to even
+    const int lstride = (a.nz + 1) & ~1;
+#define L(slot, k) Ldyn[(slot) * lstride + (k)]
 
     const Consts &c = *a.consts;
     const Tables &tb = a.tables;
@@ -230,7 +252,6 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
     const double DT = a.dt;
     const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
     const double Nt_c = c.Nt_c;
-    const double obmr = c.obmr, obmi = c.obmi;
 
     for (int64_t col = blockIdx.x; col < a.ncol; col += gridDim.x) {
         const int64_t base = col * int64_t(nz);
@@ -269,16 +290,16 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 ni = fmax(R2, gni[k] * rho);
                 if (ni <= R2) {
                     const double lami = c.cie[1] / 25.E-6;
-                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * pow(lami, bm_i));
+                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * cube(lami));
                 }
-                double lami = pow(am_i * c.cig[1] * c.oig1 * ni / ri, obmi);
+                double lami = root3(am_i * c.cig[1] * c.oig1 * ni / ri);
                 const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
                 if (xDi < 5.E-6) {
                     lami = c.cie[1] / 5.E-6;
-                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * pow(lami, bm_i));
+                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * cube(lami));
                 } else if (xDi > 300.E-6) {
                     lami = c.cie[1] / 300.E-6;
-                    ni = c.cig[0] * c.oig2 * ri / am_i * pow(lami, bm_i);
+                    ni = c.cig[0] * c.oig2 * ri / am_i * cube(lami);
                 }
             }
             if (qr1 > R1) {                                  // M:1447-1474
@@ -286,7 +307,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 rr = qr1 * rho;
                 nr = fmax(R2, gnr[k] * rho);
                 if (nr <= R2) nr = nr_from_mvd(c, rr, 1.0E-3);
-                const double lamr = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+                const double lamr = root3(am_r * c.crg[2] * c.org2 * nr / rr);
                 double mvd = (3.0 + mu_r + 0.672) / lamr;
                 if (mvd > 2.5E-3) {
                     mvd = 2.5E-3;
@@ -312,11 +333,11 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             warmlev[j] = temp >= 270.65;
             flg[j] = f;
 
-            L[V_TEMP][k] = temp;  L[V_QV][k] = qv;    L[V_RHO][k] = rho;  L[V_RC][k] = rc;
-            L[V_RI][k] = ri;      L[V_RR][k] = rr;    L[V_RS][k] = rs;    L[V_RG][k] = rg;
-            L[V_NI][k] = ni;      L[V_NR][k] = nr;    L[V_QVS][k] = qvs;  L[V_QVSI][k] = qvsi;
-            L[V_SSATW][k] = ssatw; L[V_SSATI][k] = ssati;
-            L[V_DIFFU][k] = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);   // M:1522
+            L(V_TEMP, k) = temp;  L(V_QV, k) = qv;    L(V_RHO, k) = rho;  L(V_RC, k) = rc;
+            L(V_RI, k) = ri;      L(V_RR, k) = rr;    L(V_RS, k) = rs;    L(V_RG, k) = rg;
+            L(V_NI, k) = ni;      L(V_NR, k) = nr;    L(V_QVSI, k) = qvsi;
+            L(V_SSATW, k) = ssatw; L(V_SSATI, k) = ssati;
+            L(V_DIFFU, k) = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);   // M:1522
         }
 
         // ---- no_micro early return, M:1540.  Block B has already zeroed the
@@ -356,7 +377,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int k = lane + WAVE * j;
-                if (k < nz) L[V_N0X][k] = n0[j];
+                if (k < nz) L(V_N0X, k) = n0[j];
             }
         }
 
@@ -367,11 +388,11 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             if (k >= nz) continue;
             const int f = flg[j];
             const bool L_qc = f & F_QC, L_qi = f & F_QI, L_qr = f & F_QR, L_qs = f & F_QS, L_qg = f & F_QG;
-            const double temp = L[V_TEMP][k], qv = L[V_QV][k], rho = L[V_RHO][k];
-            const double rc = L[V_RC][k], ri = L[V_RI][k], rr = L[V_RR][k], rs = L[V_RS][k], rg = L[V_RG][k];
-            const double ni = L[V_NI][k], nr = L[V_NR][k];
-            const double qvsi = L[V_QVSI][k], ssatw = L[V_SSATW][k], ssati = L[V_SSATI][k];
-            const double diffu = L[V_DIFFU][k];
+            const double temp = L(V_TEMP, k), qv = L(V_QV, k), rho = L(V_RHO, k);
+            const double rc = L(V_RC, k), ri = L(V_RI, k), rr = L(V_RR, k), rs = L(V_RS, k), rg = L(V_RG, k);
+            const double ni = L(V_NI, k), nr = L(V_NR, k);
+            const double qvsi = L(V_QVSI, k), ssatw = L(V_SSATW, k), ssati = L(V_SSATI, k);
+            const double diffu = L(V_DIFFU, k);
             const double pres = gp[k];
             const double nc = L_qc ? Nt_c : 2.;
 
@@ -395,14 +416,14 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 {   // 0th moment, M:1571-1574
                     const double la = c.sa[0] + c.sa[1] * tc0 + c.sa[4] * tc0 * tc0 + c.sa[8] * tc0 * tc0 * tc0;
                     const double b_ = c.sb[0] + c.sb[1] * tc0 + c.sb[4] * tc0 * tc0 + c.sb[8] * tc0 * tc0 * tc0;
-                    smo0 = pow(10.0, la) * pow(smo2, b_);
+                    smo0 = exp10(la) * pow(smo2, b_);
                 }
                 {   // 1st moment, M:1577-1587
                     const double la = c.sa[0] + c.sa[1] * tc0 + c.sa[2] + c.sa[3] * tc0 + c.sa[4] * tc0 * tc0 + c.sa[5]
                                     + c.sa[6] * tc0 * tc0 + c.sa[7] * tc0 + c.sa[8] * tc0 * tc0 * tc0 + c.sa[9];
                     const double b_ = c.sb[0] + c.sb[1] * tc0 + c.sb[2] + c.sb[3] * tc0 + c.sb[4] * tc0 * tc0 + c.sb[5]
                                     + c.sb[6] * tc0 * tc0 + c.sb[7] * tc0 + c.sb[8] * tc0 * tc0 * tc0 + c.sb[9];
-                    smo1 = pow(10.0, la) * pow(smo2, b_);
+                    smo1 = exp10(la) * pow(smo2, b_);
                 }
                 smoc = snow_moment(c, tc0, c.cse[0], smo2);  // M:1590-1600
                 smoe = snow_moment(c, tc0, c.cse[12], smo2); // M:1603-1613
@@ -410,20 +431,25 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             }
 
             // ---- E (per level part): graupel slope/intercept, M:1650-1653 ----
-            double ilamg = 0., N0_g = 0.;
+            double ilamg = 0., N0_g = 0., ig_bv = 0., ig11 = 0.;
             if (!iiwarm) {
-                const double N0_exp = L[V_N0X][k];
-                const double lam_exp = pow(N0_exp * am_g * c.cgg[0] / rg, c.oge1);
-                const double lamg = lam_exp * pow(c.cgg[2] * c.ogg2 * c.ogg1, c.obmg);
+                const double N0_exp = L(V_N0X, k);
+                const double lam_exp = root4(N0_exp * am_g * c.cgg[0] / rg);
+                const double lamg = lam_exp * c.lamg_fac;
                 ilamg = 1. / lamg;
-                N0_g = N0_exp / (c.cgg[1] * lam_exp) * pow(lamg, c.cge[1]);
+                N0_g = N0_exp / (c.cgg[1] * lam_exp) * lamg;          // lamg**cge(2), cge(2) = 1
+                if (L_qg) {
+                    // ilamg**bv_g is the one general power; cge(9) = 3 + bv_g, cge(10) = 2, cge(11) = 2.5 + bv_g/2
+                    ig_bv = pow(ilamg, bv_g);
+                    ig11 = ilamg * ilamg * sqrt(ilamg * ig_bv);
+                }
             }
 
             // ---- F: rain slope/intercept, M:1661-1666 ----
-            const double lamr0 = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+            const double lamr0 = root3(am_r * c.crg[2] * c.org2 * nr / rr);
             const double ilamr = 1. / lamr0;
             double mvd_r = (3.0 + mu_r + 0.672) / lamr0;
-            const double N0_r = nr * c.org2 * pow(lamr0, c.cre[1]);
+            const double N0_r = nr * c.org2 * lamr0;                // lamr**cre(2), cre(2) = 1
             const double lamr = 1. / ilamr;                  // "lamr = 1./ilamr(k)", M:1716 ...
 
             // all process rates start at zero, M:1282-1363
@@ -448,13 +474,13 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             if (L_qc) {
                 nu_c = int(lround(1000.E6 / nc)) + 2;
                 nu_c = nu_c < 15 ? nu_c : 15;
-                xDc = fmax(D0c * 1.E6, pow(rc / (am_r * nc), obmr) * 1.E6);
-                lamc = pow(nc * am_r * c.ccg[1][nu_c - 1] * c.ocg1[nu_c - 1] / rc, obmr);
+                xDc = fmax(D0c * 1.E6, root3(rc / (am_r * nc)) * 1.E6);
+                lamc = root3(nc * am_r * c.ccg[1][nu_c - 1] * c.ocg1[nu_c - 1] / rc);
                 mvd_c = (3.0 + nu_c + 0.672) / lamc;
             }
             if (rc > 0.01e-3) {                              // Berry & Reinhardt, M:1698-1712
-                const double Dc_g = (pow(c.ccg[2][nu_c - 1] * c.ocg2[nu_c - 1], obmr) / lamc) * 1.E6;
-                const double Dc_b = pow(xDc * xDc * xDc * Dc_g * Dc_g * Dc_g - xDc * xDc * xDc * xDc * xDc * xDc, 1. / 6.);
+                const double Dc_g = (c.dcg_fac[nu_c - 1] / lamc) * 1.E6;
+                const double Dc_b = root6(xDc * xDc * xDc * Dc_g * Dc_g * Dc_g - xDc * xDc * xDc * xDc * xDc * xDc);
                 const double zq = 6.25E-6 * xDc * Dc_b * Dc_b * Dc_b - 0.4;
                 const double zeta1 = 0.5 * (zq + fabs(zq));
                 const double zeta = 0.027 * rc * zeta1;
@@ -473,7 +499,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 int jc = int(mvd_c * 1.E6);
                 jc = jc < 1 ? 1 : (jc > nbins ? nbins : jc);
                 const double Ef_rw = tb.t_Efrw[(idx - 1) + nbins * (jc - 1)];
-                const double coll = pow(lamr + fv_r, -c.cre[8]);
+                const double coll = 1. / pw4(lamr + fv_r);               // (lamr+fv_r)**(-cre(9)), cre(9) = 4
                 prr_rcw = rhof * c.t1_qr_qc * Ef_rw * rc * N0_r * coll;
                 prr_rcw = fmin(rc * odts, prr_rcw);
                 pnc_rcw = rhof * c.t1_qr_qc * Ef_rw * nc * N0_r * coll;
@@ -497,8 +523,8 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 int idx_r = 1, idx_r1 = ntb_r1;
                 if (rr > c.r_r1) {
                     idx_r = decade_idx(rr, c.nir2, ntb_r);
-                    const double lam_exp = lamr * pow(c.crg[2] * c.org2 * c.org1, bm_r);
-                    const double N0_exp = c.org1 * rr / am_r * pow(lam_exp, c.cre[0]);
+                    const double lam_exp = lamr * c.lamr_exp_fac;
+                    const double N0_exp = c.org1 * rr / am_r * pw4(lam_exp);   // **cre(1) = 4
                     idx_r1 = decade_idx(N0_exp, c.nir3, ntb_r1);
                 }
                 const int idx_s = rs > c.r_s1 ? decade_idx(rs, c.nis2, ntb_s) : 1;
@@ -506,8 +532,8 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 if (rg > c.r_g1) {
                     idx_g = decade_idx(rg, c.nig2, ntb_g);
                     const double lamg = 1. / ilamg;
-                    const double lam_exp = lamg * pow(c.cgg[2] * c.ogg2 * c.ogg1, bm_g);
-                    const double N0_exp = c.ogg1 * rg / am_g * pow(lam_exp, c.cge[0]);
+                    const double lam_exp = lamg * c.lamg_exp_fac;
+                    const double N0_exp = c.ogg1 * rg / am_g * pw4(lam_exp);   // **cge(1) = 4
                     idx_g1 = decade_idx(N0_exp, c.nig3, ntb_g1);
                 }
 
@@ -541,14 +567,14 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                     }
                     if (rg >= c.r_g1 && mvd_c > D0c) {
                         const double xDg = (bm_g + mu_g + 1.) * ilamg;
-                        const double vtg = rhof * av_g * c.cgg[5] * c.ogg3 * pow(ilamg, bv_g);
+                        const double vtg = rhof * av_g * c.cgg[5] * c.ogg3 * ig_bv;
                         const double stoke_g = mvd_c * mvd_c * vtg * rho_w / (9. * visco * xDg);
                         if (xDg > D0g) {
                             double Ef_gw = 0.;
                             if (stoke_g >= 0.4 && stoke_g <= 10.) Ef_gw = 0.55 * log10(2.51 * stoke_g);
                             else if (stoke_g < 0.4)               Ef_gw = 0.0;
                             else if (stoke_g > 10)                Ef_gw = 0.77;
-                            const double ig9 = pow(ilamg, c.cge[8]);
+                            const double ig9 = cube(ilamg) * ig_bv;          // ilamg**cge(9), cge(9) = 3 + bv_g
                             prg_gcw = rhof * c.t1_qg_qc * Ef_gw * rc * N0_g * ig9;
                             pnc_gcw = rhof * c.t1_qg_qc * Ef_gw * nc * N0_g * ig9;
                             pnc_gcw = fmin(nc * odts, pnc_gcw);
@@ -635,10 +661,10 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                     }
 
                     if (L_qi) {                              // M:2116-2149 and M:2178-2202
-                        const double lami = pow(am_i * c.cig[1] * c.oig1 * ni / ri, obmi);
+                        const double lami = root3(am_i * c.cig[1] * c.oig1 * ni / ri);
                         const double ilami = 1. / lami;
                         const double xDi = fmax(c.D0i, (bm_i + mu_i + 1.) * ilami);
-                        const double xmi = am_i * pow(xDi, bm_i);
+                        const double xmi = am_i * cube(xDi);
                         const double oxmi = 1. / xmi;
                         pri_ide = C_cube * t1_subl * diffu * ssati * rvs * c.oig1 * c.cig[4] * ni * ilami;
                         const int id = (idx_i - 1) + ntb_i * (idx_i1 - 1);
@@ -669,11 +695,11 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                             pni_sci = prs_sci * oxmi;
                         }
                         if (rr >= c.r_r1 && mvd_r > 4. * xDi) {
-                            const double c9 = pow(lamr + fv_r, -c.cre[8]);
+                            const double c9 = 1. / pw4(lamr + fv_r);
                             pri_rci = rhof * c.t1_qr_qi * Ef_ri * ri * N0_r * c9;
                             pnr_rci = rhof * c.t1_qr_qi * Ef_ri * ni * N0_r * c9;
                             pni_rci = pri_rci * oxmi;
-                            prr_rci = rhof * c.t2_qr_qi * Ef_ri * ni * N0_r * pow(lamr + fv_r, -c.cre[7]);
+                            prr_rci = rhof * c.t2_qr_qi * Ef_ri * ni * N0_r * (1. / pw7(lamr + fv_r));   // **(-cre(8)), cre(8) = 7
                             prr_rci = fmin(rr * odts, prr_rci);
                             prg_rci = pri_rci + prr_rci;
                         }
@@ -688,7 +714,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                     }
                     if (L_qg && ssati < -eps) {              // graupel sublimation, M:2166-2175
                         prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g
-                                * (c.t1_qg_sd * pow(ilamg, c.cge[9]) + c.t2_qg_sd * vsc2 * rhof2 * pow(ilamg, c.cge[10]));
+                                * (c.t1_qg_sd * (ilamg * ilamg) + c.t2_qg_sd * vsc2 * rhof2 * ig11);
                         if (prg_gde < 0.) prg_gde = fmax(fmax(-rg * odts, prg_gde), rate_max);
                         else              prg_gde = fmin(prg_gde, rate_max);
                     }
@@ -714,7 +740,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                         prr_sml = (tempc * tcond - lvap0 * diffu * delQvs) * (c.t1_qs_me * smo1 + c.t2_qs_me * rhof2 * vsc2 * smof);
                         prr_sml = prr_sml + 4218. * olfus * tempc * (prr_rcs + prs_scw);
                         prr_sml = fmin(rs * odts, fmax(0., prr_sml));
-                        pnr_sml = smo0 / rs * prr_sml * pow(10.0, -0.25 * tempc);
+                        pnr_sml = smo0 / rs * prr_sml * exp10(-0.25 * tempc);
                         pnr_sml = fmin(smo0 * odts, pnr_sml);
                         if (ssati < 0.) {
                             prs_sde = C_cube * t1_subl * diffu * ssati * rvs * (c.t1_qs_sd * smo1 + c.t2_qs_sd * rhof2 * vsc2 * smof);
@@ -722,10 +748,10 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                         }
                     }
                     if (L_qg) {
-                        const double ig10 = pow(ilamg, c.cge[9]), ig11 = pow(ilamg, c.cge[10]);
+                        const double ig10 = ilamg * ilamg;
                         prr_gml = (tempc * tcond - lvap0 * diffu * delQvs) * N0_g * (c.t1_qg_me * ig10 + c.t2_qg_me * rhof2 * vsc2 * ig11);
                         prr_gml = fmin(rg * odts, fmax(0., prr_gml));
-                        pnr_gml = N0_g * c.cgg[1] * pow(ilamg, c.cge[1]) / rg * prr_gml * pow(10.0, -0.5 * tempc);
+                        pnr_gml = N0_g * c.cgg[1] * ilamg / rg * prr_gml * exp10(-0.5 * tempc);
                         if (ssati < 0.) {
                             prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g * (c.t1_qg_sd * ig10 + c.t2_qg_sd * vsc2 * rhof2 * ig11);
                             prg_gde = fmax(-rg * odts, prg_gde);
@@ -805,15 +831,15 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 if (xrc > R1) {
                     int nu = int(lround(1000.E6 / xnc)) + 2;
                     nu = nu < 15 ? nu : 15;
-                    double lc = pow(xnc * am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] / rc, obmr);
+                    double lc = root3(xnc * am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] / rc);
                     const double xD = (bm_r + nu + 1.) / lc;
                     if (xD < D0c) {
                         lc = c.cce[1][nu - 1] / D0c;
-                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * pow(lc, bm_r);
+                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * cube(lc);
                         ncten = (xnc - nc1 * rho) * odts * orho;
                     } else if (xD > D0r * 2.) {
                         lc = c.cce[1][nu - 1] / (D0r * 2.);
-                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * pow(lc, bm_r);
+                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * cube(lc);
                         ncten = (xnc - nc1 * rho) * odts * orho;
                     }
                 } else {
@@ -829,15 +855,15 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 const double xri = fmax(R1, (qi1 + qiten * DT) * rho);
                 double xni = fmax(R2, (ni1 + niten * DT) * rho);
                 if (xri > R1) {
-                    double lami = pow(am_i * c.cig[1] * c.oig1 * xni / xri, obmi);
+                    double lami = root3(am_i * c.cig[1] * c.oig1 * xni / xri);
                     const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
                     if (xDi < 5.E-6) {
                         lami = c.cie[1] / 5.E-6;
-                        xni = fmin(499.e3, c.cig[0] * c.oig2 * xri / am_i * pow(lami, bm_i));
+                        xni = fmin(499.e3, c.cig[0] * c.oig2 * xri / am_i * cube(lami));
                         niten = (xni - ni1 * rho) * odts * orho;
                     } else if (xDi > 300.E-6) {
                         lami = c.cie[1] / 300.E-6;
-                        xni = c.cig[0] * c.oig2 * xri / am_i * pow(lami, bm_i);
+                        xni = c.cig[0] * c.oig2 * xri / am_i * cube(lami);
                         niten = (xni - ni1 * rho) * odts * orho;
                     }
                 } else {
@@ -853,7 +879,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 const double xrr = fmax(R1, (qr1 + qrten * DT) * rho);
                 double xnr = fmax(R2, (nr1 + nrten * DT) * rho);
                 if (xrr > R1) {
-                    const double lr = pow(am_r * c.crg[2] * c.org2 * xnr / xrr, obmr);
+                    const double lr = root3(am_r * c.crg[2] * c.org2 * xnr / xrr);
                     mvd_r = (3.0 + mu_r + 0.672) / lr;
                     if (mvd_r > 2.5E-3) {
                         xnr = nr_from_mvd(c, xrr, 2.5E-3);
@@ -878,9 +904,9 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 tten = (lfus * ocp * (-prr_sml - prr_gml - prr_rcg - prr_rcs) + lsub * ocp * (prs_sde + prg_gde)) * orho;
             }
 
-            L[V_TTEN][k] = tten;   L[V_QVTEN][k] = qvten; L[V_QCTEN][k] = qcten; L[V_NCTEN][k] = ncten;
-            L[V_QITEN][k] = qiten; L[V_NITEN][k] = niten; L[V_QRTEN][k] = qrten; L[V_NRTEN][k] = nrten;
-            L[V_QSTEN][k] = qsten; L[V_QGTEN][k] = qgten; L[V_PRRGML][k] = prr_gml; L[V_BOOST][k] = vts_boost;
+            L(V_TTEN, k) = tten;   L(V_QVTEN, k) = qvten; L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
+            L(V_QITEN, k) = qiten; L(V_NITEN, k) = niten; L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
+            L(V_QSTEN, k) = qsten; L(V_QGTEN, k) = qgten; L(V_PRRGML, k) = prr_gml; L(V_BOOST, k) = vts_boost;
 
             if (RATES) {                                     // save_dg order of M:2967-3119 (two of them in pass 2)
                 double *g = grates + k;
@@ -915,10 +941,10 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             const double qi1 = (f & F_QI) ? gqi[k] : 0.0, ni1 = (f & F_QI) ? gni[k] : 0.0;
             const double qr1 = (f & F_QR) ? gqr[k] : 0.0, nr1 = (f & F_QR) ? gnr[k] : 0.0;
             const double qs1 = (f & F_QS) ? gqs[k] : 0.0, qg1 = (f & F_QG) ? gqg[k] : 0.0;
-            double tten = L[V_TTEN][k], qvten = L[V_QVTEN][k], qcten = L[V_QCTEN][k], ncten = L[V_NCTEN][k];
-            const double qiten = L[V_QITEN][k], niten = L[V_NITEN][k];
-            double qrten = L[V_QRTEN][k], nrten = L[V_NRTEN][k];
-            const double qsten = L[V_QSTEN][k], qgten = L[V_QGTEN][k], prr_gml = L[V_PRRGML][k];
+            double tten = L(V_TTEN, k), qvten = L(V_QVTEN, k), qcten = L(V_QCTEN, k), ncten = L(V_NCTEN, k);
+            const double qiten = L(V_QITEN, k), niten = L(V_NITEN, k);
+            double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k);
+            const double qsten = L(V_QSTEN, k), qgten = L(V_QGTEN, k), prr_gml = L(V_PRRGML, k);
             double nwfaten = 0.;
 
             // ---- K, M:2575-2655 ----
@@ -952,7 +978,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 rr = (qr1 + qrten * DT) * rho;
                 nr = fmax(R2, (nr1 + nrten * DT) * rho);
                 f2 |= F_QR;
-                const double lr = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+                const double lr = root3(am_r * c.crg[2] * c.org2 * nr / rr);
                 double mvd = (3.0 + mu_r + 0.672) / lr;
                 if (mvd > 2.5E-3)           { mvd = 2.5E-3;      nr = nr_from_mvd(c, rr, mvd); }
                 else if (mvd < D0r * 0.75)  { mvd = D0r * 0.75;  nr = nr_from_mvd(c, rr, mvd); }
@@ -973,9 +999,9 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             }
 
             // rain PSD, M:2745-2750
-            const double lamrK = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
+            const double lamrK = root3(am_r * c.crg[2] * c.org2 * nr / rr);
             const double ilamr = 1. / lamrK;
-            const double N0_r = nr * c.org2 * pow(lamrK, c.cre[1]);
+            const double N0_r = nr * c.org2 * lamrK;                 // **cre(2) = 1
 
             // ---- M: saturation adjustment, M:2780-2873 ----
             double orho = 1. / rho;
@@ -1043,7 +1069,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                     prv_rev = rr * orho * odts;
                 } else {
                     prv_rev = t1_evap * diffu * (-ssatw) * N0_r * rvs
-                            * (c.t1_qr_ev * pow(ilamr, c.cre[9]) + c.t2_qr_ev * vsc2 * rhof2 * pow(lamr + 0.5 * fv_r, -c.cre[10]));
+                            * (c.t1_qr_ev * (ilamr * ilamr) + c.t2_qr_ev * vsc2 * rhof2 * (1. / cube(lamr + 0.5 * fv_r)));   // cre(10)=2, cre(11)=3
                     const double rate_max = fmin((rr * orho * odts), (qvs - qv) * odts);
                     prv_rev = fmin(rate_max, prv_rev * orho);
                     if (prr_gml > 0.0) {
@@ -1075,11 +1101,11 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             a.nwfa[base + k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (gnwfa[k] + nwfaten * DT)));   // M:3628
             a.nifa[base + k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (gnifa[k] + 0. * DT)));       // M:3630
 
-            L[V_TTEN][k] = tten;   L[V_QCTEN][k] = qcten; L[V_NCTEN][k] = ncten;
-            L[V_QRTEN][k] = qrten; L[V_NRTEN][k] = nrten;
-            L[V_TEMP2][k] = temp;  L[V_RHO2][k] = rho;    L[V_RI2][k] = ri;  L[V_NI2][k] = ni;
-            L[V_RR2][k] = rr;      L[V_NR2][k] = nr;      L[V_RS2][k] = rs;  L[V_RG2][k] = rg;
-            L[V_XDS][k] = xDs;     L[V_OCP][k] = ocp;     L[V_LVAP][k] = lvap;
+            L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
+            L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
+            L(V_TEMP2, k) = temp;  L(V_RHO2, k) = rho;    L(V_RI2, k) = ri;  L(V_NI2, k) = ni;
+            L(V_RR2, k) = rr;      L(V_NR2, k) = nr;      L(V_RS2, k) = rs;  L(V_RG2, k) = rg;
+            L(V_XDS, k) = xDs;     L(V_OCP, k) = ocp;     L(V_LVAP, k) = lvap;
         }
 
         // ============ pass 3: fall speeds, M:3206-3354 ============
@@ -1095,18 +1121,18 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             vtr[j] = vtnr[j] = vti[j] = vtni[j] = vts[j] = vtg[j] = 0.;
             odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = false;
             if (k >= nz) continue;
-            const double rho = L[V_RHO2][k];
+            const double rho = L(V_RHO2, k);
             odz[j] = 1. / gdz[k];
             orho_[j] = 1. / rho;
-            tmp2[j] = L[V_TEMP2][k];
-            const double rr = L[V_RR2][k];
+            tmp2[j] = L(V_TEMP2, k);
+            const double rr = L(V_RR2, k);
             if (rr > R1) {                                   // M:3221-3233
                 ok[j] = true;
                 const double rhof = sqrt(rho_not / rho);
-                const double nr = L[V_NR2][k];
-                const double lamr = pow(am_r * c.crg[2] * c.org2 * nr / rr, obmr);
-                vtr[j] = rhof * av_r * c.crg[5] * c.org3 * pow(lamr, c.cre[2]) * pow(lamr + fv_r, -c.cre[5]);
-                vtnr[j] = rhof * av_r * c.crg[6] / c.crg[11] * pow(lamr, c.cre[11]) * pow(lamr + fv_r, -c.cre[6]);
+                const double nr = L(V_NR2, k);
+                const double lamr = root3(am_r * c.crg[2] * c.org2 * nr / rr);
+                vtr[j] = rhof * av_r * c.crg[5] * c.org3 * pw4(lamr) * (1. / pw5(lamr + fv_r));          // cre(3)=4, cre(6)=5
+                vtnr[j] = rhof * av_r * c.crg[6] / c.crg[11] * pw2h(lamr) * (1. / pw3h(lamr + fv_r));   // cre(12)=2.5, cre(7)=3.5
             }
         }
         carry_down2<NJ>(vtr, vtnr, ok);
@@ -1131,6 +1157,9 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
         double onstep_r = 1.0, onstep_i = 1.0, onstep_s = 1.0, onstep_g = 1.0;
         if (nstep_r > 0) onstep_r = 1. / double(nstep_r);    // M:3246
 
+        double n0x2[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) n0x2[j] = gonv_max;
         if (!iiwarm) {
             // graupel slope from the second running minimum, M:2717-2737
             {
@@ -1145,14 +1174,11 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                     const int k = lane + WAVE * j;
                     n0[j] = __builtin_inf();
                     if (k < nz)
-                        n0[j] = graupel_N0(k > k_0 && (flg2[j] & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L[V_RG2][k]);
+                        n0[j] = graupel_N0(k > k_0 && (flg2[j] & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L(V_RG2, k));
                 }
                 suffix_min<NJ>(n0);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    if (k < nz) L[V_N0X2][k] = n0[j];
-                }
+                for (int j = 0; j < NJ; ++j) n0x2[j] = n0[j];
             }
 
             // ice, M:3253-3278
@@ -1161,13 +1187,13 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 const int k = lane + WAVE * j;
                 ok[j] = false;
                 if (k >= nz) continue;
-                const double ri = L[V_RI2][k];
+                const double ri = L(V_RI2, k);
                 if (ri > R1) {
                     ok[j] = true;
-                    const double rhof = sqrt(rho_not / L[V_RHO2][k]);
-                    const double lami = pow(am_i * c.cig[1] * c.oig1 * L[V_NI2][k] / ri, obmi);
+                    const double rhof = sqrt(rho_not / L(V_RHO2, k));
+                    const double lami = root3(am_i * c.cig[1] * c.oig1 * L(V_NI2, k) / ri);
                     const double ilami = 1. / lami;
-                    const double pw = pow(ilami, bv_i);
+                    const double pw = ilami;                             // ilami**bv_i, bv_i = 1
                     vti[j] = rhof * av_i * c.cig[2] * c.oig2 * pw;
                     vtni[j] = rhof * av_i * c.cig[5] / c.cig[6] * pw;
                 }
@@ -1197,10 +1223,10 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 const int k = lane + WAVE * j;
                 ok[j] = false; dummy[j] = 0.;
                 if (k >= nz) continue;
-                if (L[V_RS2][k] > R1) {
+                if (L(V_RS2, k) > R1) {
                     ok[j] = true;
-                    const double rhof = sqrt(rho_not / L[V_RHO2][k]);
-                    const double xDs = L[V_XDS][k];
+                    const double rhof = sqrt(rho_not / L(V_RHO2, k));
+                    const double xDs = L(V_XDS, k);
                     const double Mrat = 1. / xDs;
                     double ils1 = 1. / (Mrat * Lam0 + fv_s);
                     double ils2 = 1. / (Mrat * Lam1 + fv_s);
@@ -1209,10 +1235,10 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                     const double t2_vts = Kap1 * mm * c.csg[9] * pow(ils2, c.cse[9]);
                     ils1 = 1. / (Mrat * Lam0);
                     ils2 = 1. / (Mrat * Lam1);
-                    const double t3_vts = Kap0 * c.csg[0] * pow(ils1, c.cse[0]);
+                    const double t3_vts = Kap0 * c.csg[0] * cube(ils1);          // **cse(1), cse(1) = bm_s+1 = 3
                     const double t4_vts = Kap1 * mm * c.csg[6] * pow(ils2, c.cse[6]);
                     const double v = rhof * av_s * (t1_vts + t2_vts) / (t3_vts + t4_vts);
-                    const double boost = L[V_BOOST][k];
+                    const double boost = L(V_BOOST, k);
                     if (tmp2[j] > (T_0 + 0.1))
                         vts[j] = fmax(v * boost, v * ((vtr[j] - v * boost) / (tmp2[j] - T_0)));
                     else
@@ -1243,13 +1269,13 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 const int k = lane + WAVE * j;
                 ok[j] = false; dummy[j] = 0.;
                 if (k >= nz) continue;
-                const double rg = L[V_RG2][k];
+                const double rg = L(V_RG2, k);
                 if (rg > R1) {
                     ok[j] = true;
-                    const double rhof = sqrt(rho_not / L[V_RHO2][k]);
-                    const double N0_exp = L[V_N0X2][k];
-                    const double lam_exp = pow(N0_exp * am_g * c.cgg[0] / rg, c.oge1);
-                    const double lamg = lam_exp * pow(c.cgg[2] * c.ogg2 * c.ogg1, c.obmg);
+                    const double rhof = sqrt(rho_not / L(V_RHO2, k));
+                    const double N0_exp = n0x2[j];
+                    const double lam_exp = root4(N0_exp * am_g * c.cgg[0] / rg);
+                    const double lamg = lam_exp * c.lamg_fac;
                     const double ilamg = 1. / lamg;
                     const double v = rhof * av_g * c.cgg[5] * c.ogg3 * pow(ilamg, bv_g);
                     vtg[j] = tmp2[j] > T_0 ? fmax(v, vtr[j]) : v;
@@ -1291,8 +1317,8 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             for (int j = 0; j < NJ; ++j) {
                 const int k = lane + WAVE * j;
                 const bool in = k < nz;
-                r[j] = in ? L[V_RR2][k] : 0.;   n[j] = in ? L[V_NR2][k] : 0.;
-                qt[j] = in ? L[V_QRTEN][k] : 0.; nt[j] = in ? L[V_NRTEN][k] : 0.;
+                r[j] = in ? L(V_RR2, k) : 0.;   n[j] = in ? L(V_NR2, k) : 0.;
+                qt[j] = in ? L(V_QRTEN, k) : 0.; nt[j] = in ? L(V_NRTEN, k) : 0.;
             }
             for (int s = 0; s < nstep_r; ++s) {
 #pragma unroll
@@ -1319,7 +1345,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int k = lane + WAVE * j;
-                if (k < nz) { L[V_QRTEN][k] = qt[j]; L[V_NRTEN][k] = nt[j]; }
+                if (k < nz) { L(V_QRTEN, k) = qt[j]; L(V_NRTEN, k) = nt[j]; }
             }
         }
         if (!iiwarm && c.l_sediment) {
@@ -1329,8 +1355,8 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 for (int j = 0; j < NJ; ++j) {
                     const int k = lane + WAVE * j;
                     const bool in = k < nz;
-                    r[j] = in ? L[V_RI2][k] : 0.;   n[j] = in ? L[V_NI2][k] : 0.;
-                    qt[j] = in ? L[V_QITEN][k] : 0.; nt[j] = in ? L[V_NITEN][k] : 0.;
+                    r[j] = in ? L(V_RI2, k) : 0.;   n[j] = in ? L(V_NI2, k) : 0.;
+                    qt[j] = in ? L(V_QITEN, k) : 0.; nt[j] = in ? L(V_NITEN, k) : 0.;
                 }
                 for (int s = 0; s < nstep_i; ++s) {
 #pragma unroll
@@ -1357,7 +1383,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int k = lane + WAVE * j;
-                    if (k < nz) { L[V_QITEN][k] = qt[j]; L[V_NITEN][k] = nt[j]; }
+                    if (k < nz) { L(V_QITEN, k) = qt[j]; L(V_NITEN, k) = nt[j]; }
                 }
             }
             // snow (M:3504-3529) and graupel (M:3553-3578): mass only
@@ -1372,8 +1398,8 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 for (int j = 0; j < NJ; ++j) {
                     const int k = lane + WAVE * j;
                     const bool in = k < nz;
-                    r[j] = in ? L[slot_r][k] : 0.;
-                    qt[j] = in ? L[slot_t][k] : 0.;
+                    r[j] = in ? L(slot_r, k) : 0.;
+                    qt[j] = in ? L(slot_t, k) : 0.;
                 }
                 for (int s = 0; s < nst; ++s) {
 #pragma unroll
@@ -1395,7 +1421,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const int k = lane + WAVE * j;
-                    if (k < nz) L[slot_t][k] = qt[j];
+                    if (k < nz) L(slot_t, k) = qt[j];
                 }
                 if (sp == 0) ppt_s = pp; else ppt_g = pp;
             }
@@ -1419,10 +1445,10 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             const double qr1 = (f & F_QR) ? gqr[k] : 0.0, nr1 = (f & F_QR) ? gnr[k] : 0.0;
             const double qs1 = (f & F_QS) ? gqs[k] : 0.0, qg1 = (f & F_QG) ? gqg[k] : 0.0;
             const double t1 = gt[k];
-            double tten = L[V_TTEN][k], qcten = L[V_QCTEN][k], ncten = L[V_NCTEN][k];
-            double qiten = L[V_QITEN][k], niten = L[V_NITEN][k];
-            const double qrten = L[V_QRTEN][k], nrten = L[V_NRTEN][k], qsten = L[V_QSTEN][k], qgten = L[V_QGTEN][k];
-            const double temp = L[V_TEMP2][k], rho = L[V_RHO2][k], ocp = L[V_OCP][k], lvap = L[V_LVAP][k];
+            double tten = L(V_TTEN, k), qcten = L(V_QCTEN, k), ncten = L(V_NCTEN, k);
+            double qiten = L(V_QITEN, k), niten = L(V_NITEN, k);
+            const double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k), qsten = L(V_QSTEN, k), qgten = L(V_QGTEN, k);
+            const double temp = L(V_TEMP2, k), rho = L(V_RHO2, k), ocp = L(V_OCP, k), lvap = L(V_LVAP, k);
 
             if (!iiwarm) {                                   // Q, M:3585-3605
                 const double xri = fmax(0.0, qi1 + qiten * DT);
@@ -1455,11 +1481,11 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
             } else {
                 int nu = int(lround(1000.E6 / (ncn * rho))) + 2;
                 nu = nu < 15 ? nu : 15;
-                double lc = pow(am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] * ncn / qc, obmr);
+                double lc = root3(am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] * ncn / qc);
                 const double xD = (bm_r + nu + 1.) / lc;
                 if (xD < D0c)            lc = c.cce[1][nu - 1] / D0c;
                 else if (xD > D0r * 2.)  lc = c.cce[1][nu - 1] / (D0r * 2.);
-                ncn = fmin(c.ccg[0][nu - 1] * c.ocg2[nu - 1] * qc / am_r * pow(lc, bm_r), Nt_c_max / rho);
+                ncn = fmin(c.ccg[0][nu - 1] * c.ocg2[nu - 1] * qc / am_r * cube(lc), Nt_c_max / rho);
             }
             a.qc[base + k] = qc;
             a.nc[base + k] = ncn;
@@ -1470,11 +1496,11 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 qi = 0.0;
                 nin = 0.0;
             } else {
-                double lami = pow(am_i * c.cig[1] * c.oig1 * nin / qi, obmi);
+                double lami = root3(am_i * c.cig[1] * c.oig1 * nin / qi);
                 const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
                 if (xDi < 5.E-6)          lami = c.cie[1] / 5.E-6;
                 else if (xDi > 300.E-6)   lami = c.cie[1] / 300.E-6;
-                nin = fmin(c.cig[0] * c.oig2 * qi / am_i * pow(lami, bm_i), 499.e3 / rho);
+                nin = fmin(c.cig[0] * c.oig2 * qi / am_i * cube(lami), 499.e3 / rho);
             }
             a.qi[base + k] = qi;
             a.ni[base + k] = nin;
@@ -1485,7 +1511,7 @@ __global__ __launch_bounds__(WAVE) void thompson_column_step(const StepArgs a)
                 qr = 0.0;
                 nrn = 0.0;
             } else {
-                const double lr = pow(am_r * c.crg[2] * c.org2 * nrn / qr, obmr);
+                const double lr = root3(am_r * c.crg[2] * c.org2 * nrn / qr);
                 double mvd = (3.0 + mu_r + 0.672) / lr;
                 if (mvd > 2.5E-3)           mvd = 2.5E-3;
                 else if (mvd < D0r * 0.75)  mvd = D0r * 0.75;
@@ -1508,8 +1534,9 @@ const char *column_kernel_name() { return "thompson_column_step"; }
 template <int NJ>
 static hipError_t launch_nj(const StepArgs &a, bool rates, int grid, hipStream_t s)
 {
-    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, true>), dim3(grid), dim3(WAVE), 0, s, a);
-    else       hipLaunchKernelGGL((thompson_column_step<NJ, false>), dim3(grid), dim3(WAVE), 0, s, a);
+    const size_t lds = size_t(NSLOT) * size_t((a.nz + 1) & ~1) * sizeof(double);
+    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, true>), dim3(grid), dim3(WAVE), lds, s, a);
+    else       hipLaunchKernelGGL((thompson_column_step<NJ, false>), dim3(grid), dim3(WAVE), lds, s, a);
     return hipGetLastError();
 }
 

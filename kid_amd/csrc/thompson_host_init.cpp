@@ -140,6 +140,12 @@ void host_init(int iiwarm, int l_sediment, double set_Nc, Consts &c, Bins &b)
     c.t1_qg_me = PI * 4. * C_cube * olfus * 0.86 * c.cgg[9];
     c.t2_qg_me = PI * 4. * C_cube * olfus * 0.28 * c.Sc3 * std::sqrt(av_g) * c.cgg[10];
 
+    // constant sub-expressions of the solver, evaluated once with the same libm as the reference
+    c.lamg_fac = std::pow(c.cgg[2] * c.ogg2 * c.ogg1, c.obmg);
+    c.lamr_exp_fac = std::pow(c.crg[2] * c.org2 * c.org1, bm_r);
+    c.lamg_exp_fac = std::pow(c.cgg[2] * c.ogg2 * c.ogg1, bm_g);
+    for (int n = 0; n < 15; ++n) c.dcg_fac[n] = std::pow(c.ccg[2][n] * c.ocg2[n], c.obmr);
+
     // axes, M:215-315
     decade_axis(b.r_c, ntb_c, -6);
     decade_axis(b.r_i, ntb_i, -10);

@@ -62,6 +62,11 @@ struct Consts {
     double t1_qr_ev, t2_qr_ev, t1_qs_sd, t2_qs_sd, t1_qg_sd, t2_qg_sd;
     double t1_qs_me, t2_qs_me, t1_qg_me, t2_qg_me;
     int32_t nic2, nii2, nii3, nir2, nir3, nis2, nig2, nig3;
+    // constant sub-expressions the solver evaluates at every level (hoisted to init):
+    double lamg_fac;       // (cgg(3)*ogg2*ogg1)**obmg          M:1651, M:2735
+    double lamr_exp_fac;   // (crg(3)*org2*org1)**bm_r          M:1823
+    double lamg_exp_fac;   // (cgg(3)*ogg2*ogg1)**bm_g          M:1867
+    double dcg_fac[15];    // (ccg(3,nu_c)*ocg2(nu_c))**obmr    M:1699
     double sa[10], sb[10];
     // first/last bin centres used by the efficiency-table index (M:1717, M:1907)
     double Dr1, Drn, Ds1, Dsn;
