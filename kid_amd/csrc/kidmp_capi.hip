@@ -5,7 +5,9 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -31,11 +33,28 @@ struct kidmp_ctx {
     double *d_stage = nullptr;
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
+    int debug_stop = 0;
+    int cslot = -1;
 };
 
 namespace {
 
 thread_local std::string g_err;
+std::mutex g_slot_mu;
+bool g_slot_used[MAX_CONST_SLOTS] = {};
+
+int take_slot()
+{
+    std::lock_guard<std::mutex> g(g_slot_mu);
+    for (int i = 0; i < MAX_CONST_SLOTS; ++i)
+        if (!g_slot_used[i]) { g_slot_used[i] = true; return i; }
+    return -1;
+}
+void give_slot(int i)
+{
+    std::lock_guard<std::mutex> g(g_slot_mu);
+    if (i >= 0 && i < MAX_CONST_SLOTS) g_slot_used[i] = false;
+}
 
 int fail(kidmp_ctx *c, int code, const std::string &msg)
 {
@@ -155,6 +174,7 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
     kidmp_ctx *c = new (std::nothrow) kidmp_ctx;
     if (!c) return fail(nullptr, KIDMP_ENOMEM, "kidmp_init: out of host memory");
     c->cfg = *cfg;
+    if (const char *e = getenv("KIDMP_DEBUG_STOP")) c->debug_stop = atoi(e);   // profiling aid: truncates the step
     const auto t0 = std::chrono::steady_clock::now();
     auto bail = [&](int code) { kidmp_finalize(c); return code; };
     {
@@ -174,6 +194,9 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
     INITTRY(hipMalloc((void **)&c->d_bins, sizeof(Bins)));
     INITTRY(hipMemcpy(c->d_consts, &c->hc, sizeof(Consts), hipMemcpyHostToDevice));
     INITTRY(hipMemcpy(c->d_bins, &c->hb, sizeof(Bins), hipMemcpyHostToDevice));
+    c->cslot = take_slot();
+    if (c->cslot < 0) { g_err = "kidmp_init: more than 8 live contexts in this process"; return bail(KIDMP_ESTATE); }
+    INITTRY(upload_consts(c->cslot, c->hc));
     INITTRY(alloc_tables(c->tables));
     INITTRY(build_tables(c->d_consts, c->d_bins, c->hc.iiwarm, c->tables, c->stream));
 #undef INITTRY
@@ -191,6 +214,7 @@ void kidmp_finalize(kidmp_ctx *c)
     if (c->d_bins) (void)hipFree(c->d_bins);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    give_slot(c->cslot);
     delete c;
 }
 
@@ -211,8 +235,9 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     a.qv = qv; a.qc = qc; a.qi = qi; a.qr = qr; a.qs = qs; a.qg = qg; a.ni = ni; a.nr = nr;
     a.nc = nc; a.nwfa = nwfa; a.nifa = nifa; a.t = t; a.p = p; a.dz = dz;
     a.ppt = ppt; a.rates = rates; a.nstep = nstep;
-    a.consts = ctx->d_consts; a.tables = ctx->tables;
+    a.cslot = ctx->cslot; a.tables = ctx->tables;
     a.ncol = ncol; a.nz = nz; a.dt = dt;
+    a.debug_stop = ctx->debug_stop;
     HIPTRY(ctx, launch_column_step(a, (hipStream_t)stream));
     return KIDMP_OK;
 }

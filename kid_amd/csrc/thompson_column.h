@@ -7,7 +7,8 @@
 
 namespace kidmp {
 
-constexpr int KIDMP_NRATES_ = 36;    // save_dg rates per level, order of M:2967-3119
+constexpr int KIDMP_NRATES_ = 36;
+constexpr int MAX_CONST_SLOTS = 8;   // contexts alive at once per process (constant-memory slots)    // save_dg rates per level, order of M:2967-3119
 
 // All pointers are device pointers; profiles are x[col*nz + k] (k fastest).
 struct StepArgs {
@@ -16,14 +17,16 @@ struct StepArgs {
     double *ppt;          // [ncol][4] rain, snow, graupel, ice (accumulated, M:1172)
     double *rates;        // nullptr or [ncol][36][nz]
     int32_t *nstep;       // nullptr or [ncol][4] rain, ice, snow, graupel
-    const Consts *consts; // device copy
+    int32_t cslot;        // slot of this context's Consts in constant memory (upload_consts)
     Tables tables;
     int64_t ncol;
     int32_t nz;
     double dt;
+    int32_t debug_stop;   // 0 = run everything; n = leave after pass n-1 (profiling aid, env KIDMP_DEBUG_STOP)
 };
 
 hipError_t launch_column_step(const StepArgs &a, hipStream_t s);
+hipError_t upload_consts(int slot, const Consts &c);
 const char *column_kernel_name();
 
 }  // namespace kidmp

@@ -33,6 +33,8 @@
 
 #include "thompson_column.h"
 
+#include <cstdlib>
+
 namespace kidmp {
 
 namespace {
@@ -181,6 +183,14 @@ __device__ inline double rsif(double P, double T)
     return .622 * e / (P - e);
 }
 
+// diffu = 2.11E-5*(T/273.15)**1.94*(101325./p), M:1522.  T/273.15 lies in [0.6,1.3], so
+// |1.94 ln x| < 1 and exp(1.94*log(x)) carries the rounding of log/exp straight through
+// (<= 3 ulp from libm pow) at a third of pow's cost.
+__device__ inline double diffusivity(double temp, double pres)
+{
+    return 2.11E-5 * exp(1.94 * log(temp / 273.15)) * (101325. / pres);
+}
+
 __device__ inline double visc_air(double tempc)          // M:1524-1528
 {
     return tempc >= 0.0 ? (1.718 + 0.0049 * tempc) * 1.0E-5
@@ -236,6 +246,23 @@ enum Flag { F_QC = 1, F_QI = 2, F_QR = 4, F_QS = 8, F_QG = 16 };
 
 }  // namespace
 
+// The ~3 KB of scalar constants live in the constant address space, one slot per
+// context: loads from it are invariant, so the compiler keeps them on the scalar
+// unit (s_load, no vmcnt waits) instead of issuing a vector load + full drain per use.
+__constant__ Consts g_consts[MAX_CONST_SLOTS];
+
+// A global-memory pointer whose value is the same in every lane, made explicit (readfirstlane)
+// so that p[lane offset] uses the "SGPR base + 32-bit VGPR offset" addressing form instead of a
+// per-lane 64-bit address held in VGPRs.  The result stays in the global address space.
+typedef __attribute__((address_space(1))) double gdouble;
+__device__ inline gdouble *uniform_ptr(const double *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+    return (gdouble *)((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
 template <int NJ, bool RATES>
 __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a)
 {
@@ -243,40 +270,53 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
     const int lstride = (a.nz + 1) & ~1;
 #define L(slot, k) Ldyn[(slot) * lstride + (k)]
 
-    const Consts &c = *a.consts;
+    const Consts &c = g_consts[a.cslot];
     const Tables &tb = a.tables;
     const int lane = lane_id();
     const int nz = a.nz;
+    __builtin_assume(nz >= 2 && nz <= 4 * WAVE);          // checked by launch_column_step
     const int kte = nz - 1;
+    const unsigned nzu = unsigned(nz), kteu = unsigned(kte);
     const bool iiwarm = c.iiwarm != 0;
     const double DT = a.dt;
     const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
     const double Nt_c = c.Nt_c;
 
     for (int64_t col = blockIdx.x; col < a.ncol; col += gridDim.x) {
+        if (a.debug_stop == 9) continue;                     // profiling aid: launch floor
         const int64_t base = col * int64_t(nz);
-        // the 12 state profiles are read and written in place: no __restrict__ on them
-        const double *gqv = a.qv + base, *gqc = a.qc + base, *gqi = a.qi + base, *gqr = a.qr + base,
-                     *gqs = a.qs + base, *gqg = a.qg + base, *gni = a.ni + base, *gnr = a.nr + base,
-                     *gnc = a.nc + base, *gnwfa = a.nwfa + base, *gnifa = a.nifa + base, *gt = a.t + base;
-        const double *__restrict__ gp = a.p + base, *__restrict__ gdz = a.dz + base;
-        double *grates = RATES ? a.rates + col * int64_t(KIDMP_NRATES_) * nz : nullptr;
+        // the 12 state profiles are read and written in place (no __restrict__); bases are wave-uniform
+        gdouble *gqv = uniform_ptr(a.qv + base), *gqc = uniform_ptr(a.qc + base), *gqi = uniform_ptr(a.qi + base),
+                *gqr = uniform_ptr(a.qr + base), *gqs = uniform_ptr(a.qs + base), *gqg = uniform_ptr(a.qg + base),
+                *gni = uniform_ptr(a.ni + base), *gnr = uniform_ptr(a.nr + base), *gnc = uniform_ptr(a.nc + base),
+                *gnwfa = uniform_ptr(a.nwfa + base), *gnifa = uniform_ptr(a.nifa + base), *gt = uniform_ptr(a.t + base);
+        const gdouble *gp = uniform_ptr(a.p + base), *gdz = uniform_ptr(a.dz + base);
+        gdouble *grates = RATES ? uniform_ptr(a.rates + col * int64_t(KIDMP_NRATES_) * nz) : nullptr;
 
         // ============ pass 0: blocks B + C, M:1387-1533 ============
         int flg[NJ];
         double mvdB[NJ], rgB[NJ];
         bool warmlev[NJ];
         bool any_micro = false;
+        // all first-touch HBM loads of the column are issued together (one round trip):
+        double i_t[NJ], i_qv[NJ], i_p[NJ], i_qc[NJ], i_qi[NJ], i_qr[NJ], i_qs[NJ], i_qg[NJ], i_ni[NJ], i_nr[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int k = lane + WAVE * j;
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+            const unsigned kc = k < nzu ? k : kteu;                 // clamped: loads stay unconditional
+            i_t[j] = gt[kc];   i_qv[j] = gqv[kc]; i_p[j] = gp[kc];   i_qc[j] = gqc[kc]; i_qi[j] = gqi[kc];
+            i_qr[j] = gqr[kc]; i_qs[j] = gqs[kc]; i_qg[j] = gqg[kc]; i_ni[j] = gni[kc]; i_nr[j] = gnr[kc];
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             flg[j] = 0; mvdB[j] = 0.; rgB[j] = R1; warmlev[j] = false;
-            if (k >= nz) continue;
-            const double temp = gt[k];
-            const double qv = fmax(1.E-10, gqv[k]);
-            const double pres = gp[k];
+            if (k >= nzu) continue;
+            const double temp = i_t[j];
+            const double qv = fmax(1.E-10, i_qv[j]);
+            const double pres = i_p[j];
             const double rho = 0.622 * pres / (Rgas * temp * (qv + 0.622));
-            const double qc1 = gqc[k], qi1 = gqi[k], qr1 = gqr[k], qs1 = gqs[k], qg1 = gqg[k];
+            const double qc1 = i_qc[j], qi1 = i_qi[j], qr1 = i_qr[j], qs1 = i_qs[j], qg1 = i_qg[j];
             int f = 0;
             double rc = R1, ri = R1, ni = R2, rr = R1, nr = R2, rs = R1, rg = R1;
 
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             if (qi1 > R1) {                                  // M:1420-1445
                 f |= F_QI;
                 ri = qi1 * rho;
-                ni = fmax(R2, gni[k] * rho);
+                ni = fmax(R2, i_ni[j] * rho);
                 if (ni <= R2) {
                     const double lami = c.cie[1] / 25.E-6;
                     ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * cube(lami));
@@ -305,7 +345,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             if (qr1 > R1) {                                  // M:1447-1474
                 f |= F_QR;
                 rr = qr1 * rho;
-                nr = fmax(R2, gnr[k] * rho);
+                nr = fmax(R2, i_nr[j] * rho);
                 if (nr <= R2) nr = nr_from_mvd(c, rr, 1.0E-3);
                 const double lamr = root3(am_r * c.crg[2] * c.org2 * nr / rr);
                 double mvd = (3.0 + mu_r + 0.672) / lamr;
@@ -333,11 +373,14 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             warmlev[j] = temp >= 270.65;
             flg[j] = f;
 
-            L(V_TEMP, k) = temp;  L(V_QV, k) = qv;    L(V_RHO, k) = rho;  L(V_RC, k) = rc;
-            L(V_RI, k) = ri;      L(V_RR, k) = rr;    L(V_RS, k) = rs;    L(V_RG, k) = rg;
+            L(V_TEMP, k) = temp;  L(V_QV, k) = qv;    L(V_RHO, k) = rho;
+            // the cleaned mixing ratios (block B zeroes q <= R1, M:1412...) go to LDS; pass 1 rebuilds
+            // rc..rg = q*rho from them with the same product, and block J reads them directly
+            L(V_RC, k) = (f & F_QC) ? qc1 : 0.;  L(V_RI, k) = (f & F_QI) ? qi1 : 0.;  L(V_RR, k) = (f & F_QR) ? qr1 : 0.;
+            L(V_RS, k) = (f & F_QS) ? qs1 : 0.;  L(V_RG, k) = (f & F_QG) ? qg1 : 0.;
             L(V_NI, k) = ni;      L(V_NR, k) = nr;    L(V_QVSI, k) = qvsi;
             L(V_SSATW, k) = ssatw; L(V_SSATI, k) = ssati;
-            L(V_DIFFU, k) = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);   // M:1522
+            L(V_DIFFU, k) = diffusivity(temp, pres);                 // M:1522
         }
 
         // ---- no_micro early return, M:1540.  Block B has already zeroed the
@@ -345,12 +388,12 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         if (!__any(any_micro)) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
-                if (k >= nz) continue;
-                a.qc[base + k] = 0.0; a.nc[base + k] = 0.0;
-                a.qi[base + k] = 0.0; a.ni[base + k] = 0.0;
-                a.qr[base + k] = 0.0; a.nr[base + k] = 0.0;
-                a.qs[base + k] = 0.0; a.qg[base + k] = 0.0;
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                if (k >= nzu) continue;
+                gqc[k] = 0.0; gnc[k] = 0.0;
+                gqi[k] = 0.0; gni[k] = 0.0;
+                gqr[k] = 0.0; gnr[k] = 0.0;
+                gqs[k] = 0.0; gqg[k] = 0.0;
                 if (RATES)
                     for (int r = 0; r < KIDMP_NRATES_; ++r) grates[int64_t(r) * nz + k] = 0.;
             }
@@ -368,32 +411,35 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             double n0[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                 n0[j] = __builtin_inf();
-                if (k < nz)
-                    n0[j] = graupel_N0(k > k_0 && (flg[j] & F_QR) && mvdB[j] > 100.E-6, mvdB[j], rgB[j]);
+                if (k < nzu)
+                    n0[j] = graupel_N0(int(k) > k_0 && (flg[j] & F_QR) && mvdB[j] > 100.E-6, mvdB[j], rgB[j]);
             }
             suffix_min<NJ>(n0);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
-                if (k < nz) L(V_N0X, k) = n0[j];
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                if (k < nzu) L(V_N0X, k) = n0[j];
             }
         }
 
+        if (a.debug_stop == 1) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 1: blocks D-J, M:1545-2569 ============
 #pragma unroll 1
         for (int j = 0; j < NJ; ++j) {
-            const int k = lane + WAVE * j;
-            if (k >= nz) continue;
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+            if (k >= nzu) continue;
             const int f = flg[j];
             const bool L_qc = f & F_QC, L_qi = f & F_QI, L_qr = f & F_QR, L_qs = f & F_QS, L_qg = f & F_QG;
+            const double pres = gp[k];
             const double temp = L(V_TEMP, k), qv = L(V_QV, k), rho = L(V_RHO, k);
-            const double rc = L(V_RC, k), ri = L(V_RI, k), rr = L(V_RR, k), rs = L(V_RS, k), rg = L(V_RG, k);
+            const double rc = L_qc ? L(V_RC, k) * rho : R1, ri = L_qi ? L(V_RI, k) * rho : R1,
+                         rr = L_qr ? L(V_RR, k) * rho : R1;
+            const double rs = L_qs ? L(V_RS, k) * rho : R1, rg = L_qg ? L(V_RG, k) * rho : R1;
             const double ni = L(V_NI, k), nr = L(V_NR, k);
             const double qvsi = L(V_QVSI, k), ssatw = L(V_SSATW, k), ssati = L(V_SSATI, k);
             const double diffu = L(V_DIFFU, k);
-            const double pres = gp[k];
             const double nc = L_qc ? Nt_c : 2.;
 
             // cheap thermodynamics of block C recomputed here, M:1504-1532
@@ -402,9 +448,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             const double rhof2 = sqrt(rhof);
             const double delQvs = fmax(0.0, rslf(pres, 273.15) - qv);
             const double visco = visc_air(tempc);
-            const double ocp = 1. / (Cp * (1. + 0.887 * qv));
             const double vsc2 = sqrt(rho / visco);
-            const double lvap = lvap0 + (2106.0 - 4218.0) * tempc;
             const double tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
 
             // ---- D: snow moments, M:1546-1627 ----
@@ -462,11 +506,18 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             double prs_iau = 0, prs_sci = 0, prs_rcs = 0, prs_scw = 0, prs_sde = 0, prs_ihm = 0, prs_ide = 0;
             double prg_scw = 0, prg_rfz = 0, prg_gde = 0, prg_gcw = 0, prg_rci = 0, prg_rcs = 0, prg_rcg = 0, prg_ihm = 0;
             double vts_boost = 1.5;                          // M:1751 (only read when .not.iiwarm)
+            // Number rates are final when computed (no limiter touches them except pni_ide), so they are
+            // folded into the three number tendencies at once instead of staying live until block J:
+            //   ncten = -(nc_m)*orho, niten = (ni_p + pni_ide - ni_m)*orho, nrten = (nr_p - nr_m)*orho.
+            // The terms are those of M:2422-2423, M:2457-2459, M:2508-2510; only the order of the additions
+            // differs (an ulp-level change), which frees ~30 VGPRs in the hottest part of the kernel.
+            double nc_m = 0., ni_p = 0., ni_m = 0., nr_p = 0., nr_m = 0.;
 
             // ---- G: warm-rain terms, M:1676-1726 ----
             if (L_qr && mvd_r > D0r) {
                 const double Ef_rr = 1.0 - exp(2300.0 * (mvd_r - 1950.0E-6));
                 pnr_rcr = Ef_rr * 2.0 * nr * rr;
+                nr_m += pnr_rcr;
             }
             double mvd_c = D0c;
             int nu_c = 15;
@@ -491,6 +542,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 prr_wau = fmin(rc * odts, prr_wau);
                 pnr_wau = prr_wau / (am_r * nu_c * D0r * D0r * D0r);
                 pnc_wau = fmin(nc * odts, prr_wau / (am_r * mvd_c * mvd_c * mvd_c));
+                nr_p += pnr_wau;
+                nc_m += pnc_wau;
             }
             if (L_qr && mvd_r > D0r && mvd_c > D0c) {        // accretion, M:1715-1726
                 int idx = 1 + int(nbins * log(mvd_r / c.Dr1) / log(c.Drn / c.Dr1));
@@ -504,6 +557,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 prr_rcw = fmin(rc * odts, prr_rcw);
                 pnc_rcw = rhof * c.t1_qr_qc * Ef_rw * nc * N0_r * coll;
                 pnc_rcw = fmin(nc * odts, pnc_rcw);
+                nc_m += pnc_rcw;
             }
             // rain/snow/graupel scavenging of aerosols (M:1729-1740, M:1938-1959) only
             // feeds nwfaten/nifaten under is_aerosol_aware (M:2398-2408): not computed.
@@ -564,6 +618,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         prs_scw = rhof * c.t1_qs_qc * Ef_sw * rc * smoe;
                         pnc_scw = rhof * c.t1_qs_qc * Ef_sw * nc * smoe;
                         pnc_scw = fmin(nc * odts, pnc_scw);
+                        nc_m += pnc_scw;
                     }
                     if (rg >= c.r_g1 && mvd_c > D0c) {
                         const double xDg = (bm_g + mu_g + 1.) * ilamg;
@@ -578,6 +633,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                             prg_gcw = rhof * c.t1_qg_qc * Ef_gw * rc * N0_g * ig9;
                             pnc_gcw = rhof * c.t1_qg_qc * Ef_gw * nc * N0_g * ig9;
                             pnc_gcw = fmin(nc * odts, pnc_gcw);
+                            nc_m += pnc_gcw;
                         }
                     }
                 }
@@ -604,6 +660,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                             pnr_rcs = r[7] + r[9];
                         }
                         pnr_rcs = fmin(nr * odts, pnr_rcs);
+                        nr_m += pnr_rcs;
                     }
                     if (rg >= c.r_g1) {
                         const int64_t id = (idx_g1 - 1) + int64_t(ntb_g1) * ((idx_g - 1) + int64_t(ntb_g) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_r - 1)));
@@ -620,6 +677,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                             prg_rcg = -prr_rcg;
                             pnr_rcg = -5. * r[3];
                         }
+                        nr_m += pnr_rcg;
                     }
                 }
 
@@ -635,10 +693,14 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         pni_rfz = r[2] * odts;
                         pnr_rfz = r[3] * odts;
                         pnr_rfz = fmin(nr * odts, pnr_rfz);
+                        nr_m += pnr_rfz;
+                        ni_p += pni_rfz;
                     } else if (rr > R1 && temp < HGFR) {
                         pri_rfz = rr * odts;
                         pnr_rfz = nr * odts;
                         pni_rfz = pnr_rfz;
+                        nr_m += pnr_rfz;
+                        ni_p += pni_rfz;
                     }
                     if (rc > c.r_c1) {
                         const int id = (idx_c - 1) + ntb_c * (idx_tc - 1);
@@ -646,9 +708,13 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         pri_wfz = fmin(rc * odts, pri_wfz);
                         pni_wfz = tb.tni_qcfz[id] * odts;
                         pni_wfz = fmin(fmin(Nt_c * odts, pri_wfz / (2. * xm0i)), pni_wfz);
+                        nc_m += pni_wfz;
+                        ni_p += pni_wfz;
                     } else if (rc > R1 && temp < HGFR) {
                         pri_wfz = rc * odts;
                         pni_wfz = nc * odts;
+                        nc_m += pni_wfz;
+                        ni_p += pni_wfz;
                     }
 
                     // Cooper nucleation, M:2090-2101
@@ -658,6 +724,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         pni_inu = 0.5 * (xnc - xni + fabs(xnc - xni)) * odts;
                         pri_inu = fmin(rate_max, xm0i * pni_inu);
                         pni_inu = pri_inu / xm0i;
+                        ni_p += pni_inu;
                     }
 
                     if (L_qi) {                              // M:2116-2149 and M:2178-2202
@@ -690,15 +757,19 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                             pni_iau = tb.tni_iaus[id] * odts;
                             pni_iau = fmin(ni * .95 * odts, pni_iau);
                         }
+                        ni_m += pni_iau;
                         if (rs >= c.r_s1) {
                             prs_sci = c.t1_qs_qi * rhof * Ef_si * ri * smoe;
                             pni_sci = prs_sci * oxmi;
+                            ni_m += pni_sci;
                         }
                         if (rr >= c.r_r1 && mvd_r > 4. * xDi) {
                             const double c9 = 1. / pw4(lamr + fv_r);
                             pri_rci = rhof * c.t1_qr_qi * Ef_ri * ri * N0_r * c9;
                             pnr_rci = rhof * c.t1_qr_qi * Ef_ri * ni * N0_r * c9;
                             pni_rci = pri_rci * oxmi;
+                            ni_m += pni_rci;
+                            nr_m += pnr_rci;
                             prr_rci = rhof * c.t2_qr_qi * Ef_ri * ni * N0_r * (1. / pw7(lamr + fv_r));   // **(-cre(8)), cre(8) = 7
                             prr_rci = fmin(rr * odts, prr_rci);
                             prg_rci = pri_rci + prr_rci;
@@ -725,6 +796,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         else if (tempc > -8.0 && tempc < -5.0)  tf = 0.33333333 * (8.0 + tempc);
                         pni_ihm = 3.5E8 * tf * prg_gcw;
                         pri_ihm = xm0i * pni_ihm;
+                        ni_p += pni_ihm;
                         prs_ihm = prs_scw / (prs_scw + prg_gcw) * pri_ihm;
                         prg_ihm = prg_gcw / (prs_scw + prg_gcw) * pri_ihm;
                     }
@@ -742,6 +814,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         prr_sml = fmin(rs * odts, fmax(0., prr_sml));
                         pnr_sml = smo0 / rs * prr_sml * exp10(-0.25 * tempc);
                         pnr_sml = fmin(smo0 * odts, pnr_sml);
+                        nr_p += pnr_sml;
                         if (ssati < 0.) {
                             prs_sde = C_cube * t1_subl * diffu * ssati * rvs * (c.t1_qs_sd * smo1 + c.t2_qs_sd * rhof2 * vsc2 * smof);
                             prs_sde = fmax(-rs * odts, prs_sde);
@@ -752,6 +825,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         prr_gml = (tempc * tcond - lvap0 * diffu * delQvs) * N0_g * (c.t1_qg_me * ig10 + c.t2_qg_me * rhof2 * vsc2 * ig11);
                         prr_gml = fmin(rg * odts, fmax(0., prr_gml));
                         pnr_gml = N0_g * c.cgg[1] * ilamg / rg * prr_gml * exp10(-0.5 * tempc);
+                        nr_p += pnr_gml;
                         if (ssati < 0.) {
                             prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g * (c.t1_qg_sd * ig10 + c.t2_qg_sd * vsc2 * rhof2 * ig11);
                             prg_gde = fmax(-rg * odts, prg_gde);
@@ -764,6 +838,10 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     }
                 }
             }
+
+            // inputs of block J: requested now, consumed after the limiters
+            const double nc1_raw = gnc[k], ni1_raw = gni[k], nr1_raw = gnr[k];
+            const double qc1 = L(V_RC, k), qi1 = L(V_RI, k), qr1 = L(V_RR, k);
 
             // ---- I: conservation limiters, M:2297-2385 ----
             {
@@ -817,14 +895,14 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 
             // ---- J: tendencies and number re-balancing, M:2393-2567 ----
             const double orho = 1. / rho;
+            const double ocp = 1. / (Cp * (1. + 0.887 * qv));            // M:1529
+            const double lvap = lvap0 + (2106.0 - 4218.0) * tempc;       // M:1531
             const double lfus2 = lsub - lvap;
-            const double qc1 = L_qc ? gqc[k] : 0.0, nc1 = L_qc ? gnc[k] : 0.0;     // as cleaned by block B
-            const double qi1 = L_qi ? gqi[k] : 0.0, ni1 = L_qi ? gni[k] : 0.0;
-            const double qr1 = L_qr ? gqr[k] : 0.0, nr1 = L_qr ? gnr[k] : 0.0;
+            const double nc1 = L_qc ? nc1_raw : 0.0, ni1 = L_qi ? ni1_raw : 0.0, nr1 = L_qr ? nr1_raw : 0.0;   // as cleaned by block B
 
             const double qvten = (-pri_inu - pri_iha - pri_ide - prs_ide - prs_sde - prg_gde) * orho;
             const double qcten = (-prr_wau - pri_wfz - prr_rcw - prs_scw - prg_scw - prg_gcw) * orho;
-            double ncten = (-pnc_wau - pnc_rcw - pni_wfz - pnc_scw - pnc_gcw) * orho;
+            double ncten = (-nc_m) * orho;                   // M:2422-2424
             {
                 const double xrc = fmax(R1, (qc1 + qcten * DT) * rho);
                 double xnc = fmax(2., (nc1 + ncten * DT) * rho);
@@ -850,7 +928,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             }
 
             const double qiten = (pri_inu + pri_iha + pri_ihm + pri_wfz + pri_rfz + pri_ide - prs_iau - prs_sci - pri_rci) * orho;
-            double niten = (pni_inu + pni_iha + pni_ihm + pni_wfz + pni_rfz + pni_ide - pni_iau - pni_sci - pni_rci) * orho;
+            double niten = (ni_p + pni_iha + pni_ide - ni_m) * orho;          // M:2457-2460
             {
                 const double xri = fmax(R1, (qi1 + qiten * DT) * rho);
                 double xni = fmax(R2, (ni1 + niten * DT) * rho);
@@ -874,7 +952,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             }
 
             double qrten = (prr_wau + prr_rcw + prr_sml + prr_gml + prr_rcs + prr_rcg - prg_rfz - pri_rfz - prr_rci) * orho;
-            double nrten = (pnr_wau + pnr_sml + pnr_gml - (pnr_rfz + pnr_rcr + pnr_rcg + pnr_rcs + pnr_rci)) * orho;
+            double nrten = (nr_p - nr_m) * orho;             // M:2508-2511
             {
                 const double xrr = fmax(R1, (qr1 + qrten * DT) * rho);
                 double xnr = fmax(R2, (nr1 + nrten * DT) * rho);
@@ -909,7 +987,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             L(V_QSTEN, k) = qsten; L(V_QGTEN, k) = qgten; L(V_PRRGML, k) = prr_gml; L(V_BOOST, k) = vts_boost;
 
             if (RATES) {                                     // save_dg order of M:2967-3119 (two of them in pass 2)
-                double *g = grates + k;
+                gdouble *g = grates + k;
                 if (!iiwarm) {
                     const double v[30] = {pri_inu, pri_ide, prs_ide, prs_sde, prg_gde, pri_wfz, prs_scw, prg_scw, prg_gcw, pri_ihm,
                                           pri_rfz, prs_iau, prs_sci, pri_rci, pni_inu, pni_ihm, pni_wfz, pni_rfz, pni_ide, pni_iau,
@@ -927,14 +1005,15 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             }
         }
 
+        if (a.debug_stop == 2) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 2: blocks K, L(snow), rain PSD, M, N; M:2574-2960 ============
         double mvdK[NJ];
         int flg2[NJ];
 #pragma unroll 1
         for (int j = 0; j < NJ; ++j) {
-            const int k = lane + WAVE * j;
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             flg2[j] = 0; mvdK[j] = 0.; warmlev[j] = false;
-            if (k >= nz) continue;
+            if (k >= nzu) continue;
             const int f = flg[j];
             const double t1 = gt[k], qv1 = gqv[k], pres = gp[k];
             const double qc1 = (f & F_QC) ? gqc[k] : 0.0;
@@ -958,7 +1037,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             double qvs = rslf(pres, temp);
             double ssatw = qv / qvs - 1.;
             if (fabs(ssatw) < eps) ssatw = 0.0;
-            double diffu = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);
+            double diffu = diffusivity(temp, pres);
             double visco = visc_air(tempc);
             double vsc2 = sqrt(rho / visco);
             double lvap = lvap0 + (2106.0 - 4218.0) * tempc;
@@ -1047,7 +1126,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 orho = 1. / rho;
                 rhof = sqrt(rho_not * orho);
                 rhof2 = sqrt(rhof);
-                diffu = 2.11E-5 * pow(temp / 273.15, 1.94) * (101325. / pres);
+                diffu = diffusivity(temp, pres);
                 visco = visc_air(tempc);
                 vsc2 = sqrt(rho / visco);
                 lvap = lvap0 + (2106.0 - 4218.0) * tempc;
@@ -1097,9 +1176,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             }
 
             // qv and the (inert) aerosol numbers are final here: blocks O-Q do not touch them
-            a.qv[base + k] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
-            a.nwfa[base + k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (gnwfa[k] + nwfaten * DT)));   // M:3628
-            a.nifa[base + k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (gnifa[k] + 0. * DT)));       // M:3630
+            gqv[k] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
+            gnwfa[k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (gnwfa[k] + nwfaten * DT)));   // M:3628
+            gnifa[k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (gnifa[k] + 0. * DT)));       // M:3630
 
             L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
             L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
@@ -1108,6 +1187,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             L(V_XDS, k) = xDs;     L(V_OCP, k) = ocp;     L(V_LVAP, k) = lvap;
         }
 
+        if (a.debug_stop == 3) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 3: fall speeds, M:3206-3354 ============
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
         double odz[NJ], orho_[NJ], tmp2[NJ];
@@ -1117,10 +1197,10 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int k = lane + WAVE * j;
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             vtr[j] = vtnr[j] = vti[j] = vtni[j] = vts[j] = vtg[j] = 0.;
             odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = false;
-            if (k >= nz) continue;
+            if (k >= nzu) continue;
             const double rho = L(V_RHO2, k);
             odz[j] = 1. / gdz[k];
             orho_[j] = 1. / rho;
@@ -1140,11 +1220,11 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             int ns = 0, ks = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
-                if (k >= nz) continue;
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                if (k >= nzu) continue;
                 const double vm = fmax(vtr[j], vtnr[j]);
                 if (vm > 1.E-3) {                            // M:3239-3243
-                    ks = k;
+                    ks = int(k);
                     const double delta_tp = gdz[k] / vm;
                     const int n1 = int(DT / delta_tp + 1.);
                     ns = n1 > ns ? n1 : ns;
@@ -1171,10 +1251,10 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 double n0[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                     n0[j] = __builtin_inf();
-                    if (k < nz)
-                        n0[j] = graupel_N0(k > k_0 && (flg2[j] & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L(V_RG2, k));
+                    if (k < nzu)
+                        n0[j] = graupel_N0(int(k) > k_0 && (flg2[j] & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L(V_RG2, k));
                 }
                 suffix_min<NJ>(n0);
 #pragma unroll
@@ -1184,9 +1264,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             // ice, M:3253-3278
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                 ok[j] = false;
-                if (k >= nz) continue;
+                if (k >= nzu) continue;
                 const double ri = L(V_RI2, k);
                 if (ri > R1) {
                     ok[j] = true;
@@ -1203,9 +1283,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 int ns = 0, ks = 0;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    if (k < nz && vti[j] > 1.E-3) {
-                        ks = k;
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    if (k < nzu && vti[j] > 1.E-3) {
+                        ks = int(k);
                         const int n1 = int(DT / (gdz[k] / vti[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
@@ -1220,9 +1300,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             double dummy[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                 ok[j] = false; dummy[j] = 0.;
-                if (k >= nz) continue;
+                if (k >= nzu) continue;
                 if (L(V_RS2, k) > R1) {
                     ok[j] = true;
                     const double rhof = sqrt(rho_not / L(V_RHO2, k));
@@ -1250,9 +1330,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 int ns = 0, ks = 0;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    if (k < nz && vts[j] > 1.E-3) {
-                        ks = k;
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    if (k < nzu && vts[j] > 1.E-3) {
+                        ks = int(k);
                         const int n1 = int(DT / (gdz[k] / vts[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
@@ -1266,9 +1346,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             // graupel, M:3321-3343
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                 ok[j] = false; dummy[j] = 0.;
-                if (k >= nz) continue;
+                if (k >= nzu) continue;
                 const double rg = L(V_RG2, k);
                 if (rg > R1) {
                     ok[j] = true;
@@ -1286,9 +1366,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 int ns = 0, ks = 0;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    if (k < nz && vtg[j] > 1.E-3) {
-                        ks = k;
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    if (k < nzu && vtg[j] > 1.E-3) {
+                        ks = int(k);
                         const int n1 = int(DT / (gdz[k] / vtg[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
@@ -1309,14 +1389,15 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             a.nstep[col * 4 + 2] = nstep_s; a.nstep[col * 4 + 3] = nstep_g;
         }
 
+        if (a.debug_stop == 4) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 4: sedimentation sweeps, M:3365-3578 ============
         double ppt_r = 0., ppt_s = 0., ppt_g = 0., ppt_i = 0.;
         {   // rain (never gated by l_sediment), M:3365-3399
             double r[NJ], n[NJ], qt[NJ], nt[NJ], sr[NJ], sn[NJ], ur[NJ], un[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
-                const bool in = k < nz;
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                const bool in = k < nzu;
                 r[j] = in ? L(V_RR2, k) : 0.;   n[j] = in ? L(V_NR2, k) : 0.;
                 qt[j] = in ? L(V_QRTEN, k) : 0.; nt[j] = in ? L(V_NRTEN, k) : 0.;
             }
@@ -1327,13 +1408,13 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 shift_from_above<NJ>(sn, un);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    if (k == kte) {
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    if (k == kteu) {
                         qt[j] = qt[j] - sr[j] * odz[j] * onstep_r * orho_[j];
                         nt[j] = nt[j] - sn[j] * odz[j] * onstep_r * orho_[j];
                         r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onstep_r);
                         n[j] = fmax(R2, n[j] - sn[j] * odz[j] * DT * onstep_r);
-                    } else if (k <= ksed_r) {
+                    } else if (int(k) <= ksed_r) {
                         qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_r * orho_[j];
                         nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_r * orho_[j];
                         r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_r);
@@ -1344,8 +1425,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int k = lane + WAVE * j;
-                if (k < nz) { L(V_QRTEN, k) = qt[j]; L(V_NRTEN, k) = nt[j]; }
+                const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                if (k < nzu) { L(V_QRTEN, k) = qt[j]; L(V_NRTEN, k) = nt[j]; }
             }
         }
         if (!iiwarm && c.l_sediment) {
@@ -1353,8 +1434,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 double r[NJ], n[NJ], qt[NJ], nt[NJ], sr[NJ], sn[NJ], ur[NJ], un[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    const bool in = k < nz;
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    const bool in = k < nzu;
                     r[j] = in ? L(V_RI2, k) : 0.;   n[j] = in ? L(V_NI2, k) : 0.;
                     qt[j] = in ? L(V_QITEN, k) : 0.; nt[j] = in ? L(V_NITEN, k) : 0.;
                 }
@@ -1365,13 +1446,13 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     shift_from_above<NJ>(sn, un);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const int k = lane + WAVE * j;
-                        if (k == kte) {
+                        const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                        if (k == kteu) {
                             qt[j] = qt[j] - sr[j] * odz[j] * onstep_i * orho_[j];
                             nt[j] = nt[j] - sn[j] * odz[j] * onstep_i * orho_[j];
                             r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onstep_i);
                             n[j] = fmax(R2, n[j] - sn[j] * odz[j] * DT * onstep_i);
-                        } else if (k <= ksed_i) {
+                        } else if (int(k) <= ksed_i) {
                             qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_i * orho_[j];
                             nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_i * orho_[j];
                             r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_i);
@@ -1382,8 +1463,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    if (k < nz) { L(V_QITEN, k) = qt[j]; L(V_NITEN, k) = nt[j]; }
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    if (k < nzu) { L(V_QITEN, k) = qt[j]; L(V_NITEN, k) = nt[j]; }
                 }
             }
             // snow (M:3504-3529) and graupel (M:3553-3578): mass only
@@ -1396,8 +1477,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 double pp = 0.;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    const bool in = k < nz;
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    const bool in = k < nzu;
                     r[j] = in ? L(slot_r, k) : 0.;
                     qt[j] = in ? L(slot_t, k) : 0.;
                 }
@@ -1407,11 +1488,11 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     shift_from_above<NJ>(sr, ur);
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
-                        const int k = lane + WAVE * j;
-                        if (k == kte) {
+                        const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                        if (k == kteu) {
                             qt[j] = qt[j] - sr[j] * odz[j] * onst * orho_[j];
                             r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onst);
-                        } else if (k <= ksed) {
+                        } else if (int(k) <= ksed) {
                             qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onst * orho_[j];
                             r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onst);
                         }
@@ -1420,8 +1501,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const int k = lane + WAVE * j;
-                    if (k < nz) L(slot_t, k) = qt[j];
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    if (k < nzu) L(slot_t, k) = qt[j];
                 }
                 if (sp == 0) ppt_s = pp; else ppt_g = pp;
             }
@@ -1434,11 +1515,12 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             pp[3] = pp[3] + ppt_i;
         }
 
+        if (a.debug_stop == 5) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 5: blocks Q + R, M:3584-3686 ============
 #pragma unroll 1
         for (int j = 0; j < NJ; ++j) {
-            const int k = lane + WAVE * j;
-            if (k >= nz) continue;
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+            if (k >= nzu) continue;
             const int f = flg[j];
             const double qc1 = (f & F_QC) ? gqc[k] : 0.0, nc1 = (f & F_QC) ? gnc[k] : 0.0;
             const double qi1 = (f & F_QI) ? gqi[k] : 0.0, ni1 = (f & F_QI) ? gni[k] : 0.0;
@@ -1472,7 +1554,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             }
 
             // R, M:3624-3685
-            a.t[base + k] = t1 + tten * DT;
+            gt[k] = t1 + tten * DT;
             double qc = qc1 + qcten * DT;
             double ncn = fmax(2. / rho, nc1 + ncten * DT);
             if (qc <= R1) {
@@ -1487,8 +1569,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 else if (xD > D0r * 2.)  lc = c.cce[1][nu - 1] / (D0r * 2.);
                 ncn = fmin(c.ccg[0][nu - 1] * c.ocg2[nu - 1] * qc / am_r * cube(lc), Nt_c_max / rho);
             }
-            a.qc[base + k] = qc;
-            a.nc[base + k] = ncn;
+            gqc[k] = qc;
+            gnc[k] = ncn;
 
             double qi = qi1 + qiten * DT;
             double nin = fmax(R2 / rho, ni1 + niten * DT);
@@ -1502,8 +1584,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 else if (xDi > 300.E-6)   lami = c.cie[1] / 300.E-6;
                 nin = fmin(c.cig[0] * c.oig2 * qi / am_i * cube(lami), 499.e3 / rho);
             }
-            a.qi[base + k] = qi;
-            a.ni[base + k] = nin;
+            gqi[k] = qi;
+            gni[k] = nin;
 
             double qr = qr1 + qrten * DT;
             double nrn = fmax(R2 / rho, nr1 + nrten * DT);
@@ -1517,19 +1599,25 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 else if (mvd < D0r * 0.75)  mvd = D0r * 0.75;
                 nrn = nr_from_mvd(c, qr, mvd);
             }
-            a.qr[base + k] = qr;
-            a.nr[base + k] = nrn;
+            gqr[k] = qr;
+            gnr[k] = nrn;
 
             const double qs = qs1 + qsten * DT;
-            a.qs[base + k] = qs <= R1 ? 0.0 : qs;
+            gqs[k] = qs <= R1 ? 0.0 : qs;
             const double qg = qg1 + qgten * DT;
-            a.qg[base + k] = qg <= R1 ? 0.0 : qg;
+            gqg[k] = qg <= R1 ? 0.0 : qg;
         }
         __syncthreads();     // LDS is reused by the next column of this block
     }
 }
 
 const char *column_kernel_name() { return "thompson_column_step"; }
+
+hipError_t upload_consts(int slot, const Consts &c)
+{
+    if (slot < 0 || slot >= MAX_CONST_SLOTS) return hipErrorInvalidValue;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_consts), &c, sizeof(Consts), size_t(slot) * sizeof(Consts), hipMemcpyHostToDevice);
+}
 
 template <int NJ>
 static hipError_t launch_nj(const StepArgs &a, bool rates, int grid, hipStream_t s)
@@ -1545,7 +1633,8 @@ hipError_t launch_column_step(const StepArgs &a, hipStream_t s)
     if (a.ncol <= 0) return hipSuccess;
     if (a.nz < 2 || a.nz > 4 * WAVE) return hipErrorInvalidValue;
     const int nj = (a.nz + WAVE - 1) / WAVE;
-    const int64_t maxgrid = int64_t(1) << 20;
+    int64_t maxgrid = int64_t(1) << 20;
+    if (const char *e = getenv("KIDMP_GRID_CAP")) maxgrid = atoll(e) > 0 ? atoll(e) : maxgrid;   // tuning aid
     const int grid = int(a.ncol < maxgrid ? a.ncol : maxgrid);
     const bool rates = a.rates != nullptr;
     switch (nj) {
