@@ -42,63 +42,108 @@ namespace {
 constexpr int WAVE = 64;
 
 // ---------------- wave primitives ----------------
+// Cross-lane work stays on the VALU: DPP row shifts inside the four 16-lane rows, v_readlane to
+// stitch rows (and the NJ level groups) together.  No LDS round trips (ds_bpermute) on these paths.
 __device__ inline int lane_id() { return threadIdx.x & (WAVE - 1); }
 
-__device__ inline int wave_max_i(int v)
+constexpr int DPP_ROW_SHL = 0x100;      // row_shl:n  lane i <- lane i+n of its 16-lane row
+constexpr int DPP_WAVE_SHL1 = 0x130;    // wave_shl:1 lane i <- lane i+1 across the wave (gfx9 family)
+
+template <int CTRL>
+__device__ inline int dpp_i(int old, int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(v, d, WAVE);
-        v = o > v ? o : v;
-    }
-    return v;
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false);   // lanes without a source keep `old`
+}
+template <int CTRL>
+__device__ inline double dpp_d(double old, double v)
+{
+    const long long ov = __double_as_longlong(old), vv = __double_as_longlong(v);
+    const unsigned lo = unsigned(dpp_i<CTRL>(int(unsigned(ov)), int(unsigned(vv))));
+    const unsigned hi = unsigned(dpp_i<CTRL>(int(unsigned(ov >> 32)), int(unsigned(vv >> 32))));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ inline double readlane_d(double v, int l)
+{
+    const long long vv = __double_as_longlong(v);
+    const unsigned lo = unsigned(__builtin_amdgcn_readlane(int(unsigned(vv)), l));
+    const unsigned hi = unsigned(__builtin_amdgcn_readlane(int(unsigned(vv >> 32)), l));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// x[j] <- min over all levels at or above (lane + 64 j)
+// max over the wave of a non-negative int (result uniform)
+__device__ inline int wave_max_i(int v)
+{
+    v = max(v, dpp_i<DPP_ROW_SHL + 1>(0, v));
+    v = max(v, dpp_i<DPP_ROW_SHL + 2>(0, v));
+    v = max(v, dpp_i<DPP_ROW_SHL + 4>(0, v));
+    v = max(v, dpp_i<DPP_ROW_SHL + 8>(0, v));                            // lanes 0,16,32,48 hold their row's max
+    const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16),
+              r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
+// x[j] <- min over all levels at or above (lane + 64 j)   (suffix scan from the column top)
 template <int NJ>
 __device__ inline void suffix_min(double (&x)[NJ])
 {
-    const int lane = lane_id();
-    double carry = __builtin_inf();
+    const int row = lane_id() >> 4;
+    const double inf = __builtin_inf();
+    double carry = inf;                                                  // min over the level groups above
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
         double v = x[j];
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const double o = __shfl_down(v, d, WAVE);
-            if (lane + d < WAVE) v = fmin(v, o);
-        }
-        v = fmin(v, carry);
+        v = fmin(v, dpp_d<DPP_ROW_SHL + 1>(inf, v));
+        v = fmin(v, dpp_d<DPP_ROW_SHL + 2>(inf, v));
+        v = fmin(v, dpp_d<DPP_ROW_SHL + 4>(inf, v));
+        v = fmin(v, dpp_d<DPP_ROW_SHL + 8>(inf, v));                     // suffix min inside each row
+        const double t3 = fmin(readlane_d(v, 48), carry);                // rows 3.., incl. carry
+        const double t2 = fmin(readlane_d(v, 32), t3);
+        const double t1 = fmin(readlane_d(v, 16), t2);
+        const double above = row == 3 ? carry : (row == 2 ? t3 : (row == 1 ? t2 : t1));
+        v = fmin(v, above);
         x[j] = v;
-        carry = __shfl(v, 0, WAVE);
+        carry = fmin(readlane_d(v, 0), carry);
     }
 }
 
-// v*[j] <- value at the nearest level at or above that has ok, else 0
+// a[j], b[j] <- value at the nearest level at or above that has ok, else 0
 // (the "vtXk(k) = vtXk(k+1)" carry of M:3235, 3267, 3307, 3333)
 template <int NJ>
 __device__ inline void carry_down2(double (&a)[NJ], double (&b)[NJ], const bool (&okin)[NJ])
 {
-    const int lane = lane_id();
+    const int row = lane_id() >> 4;
     double ca = 0., cb = 0.;
     int cok = 0;
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
         double va = a[j], vb = b[j];
         int ok = okin[j] ? 1 : 0;
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            const double oa = __shfl_down(va, d, WAVE);
-            const double ob = __shfl_down(vb, d, WAVE);
-            const int oo = __shfl_down(ok, d, WAVE);
-            if (lane + d < WAVE && !ok) { va = oa; vb = ob; ok = oo; }
+#define CARRY_STEP(N)                                                     \
+        {                                                                 \
+            const int oo = dpp_i<DPP_ROW_SHL + N>(0, ok);                 \
+            const double oa = dpp_d<DPP_ROW_SHL + N>(0., va);             \
+            const double ob = dpp_d<DPP_ROW_SHL + N>(0., vb);             \
+            if (!ok) { va = oa; vb = ob; ok = oo; }                       \
         }
-        if (!ok) { va = ca; vb = cb; ok = cok; }
+        CARRY_STEP(1) CARRY_STEP(2) CARRY_STEP(4) CARRY_STEP(8)
+#undef CARRY_STEP
+        // row heads (lanes 16, 32, 48) now hold their row's nearest valid value; chain them downward
+        int k3 = __builtin_amdgcn_readlane(ok, 48);  double a3 = readlane_d(va, 48), b3 = readlane_d(vb, 48);
+        if (!k3) { k3 = cok; a3 = ca; b3 = cb; }
+        int k2 = __builtin_amdgcn_readlane(ok, 32);  double a2 = readlane_d(va, 32), b2 = readlane_d(vb, 32);
+        if (!k2) { k2 = k3; a2 = a3; b2 = b3; }
+        int k1 = __builtin_amdgcn_readlane(ok, 16);  double a1 = readlane_d(va, 16), b1 = readlane_d(vb, 16);
+        if (!k1) { k1 = k2; a1 = a2; b1 = b2; }
+        if (!ok) {
+            ok = row == 3 ? cok : (row == 2 ? k3 : (row == 1 ? k2 : k1));
+            va = row == 3 ? ca : (row == 2 ? a3 : (row == 1 ? a2 : a1));
+            vb = row == 3 ? cb : (row == 2 ? b3 : (row == 1 ? b2 : b1));
+        }
         a[j] = ok ? va : 0.;
         b[j] = ok ? vb : 0.;
-        ca = __shfl(va, 0, WAVE);
-        cb = __shfl(vb, 0, WAVE);
-        cok = __shfl(ok, 0, WAVE);
+        cok = __builtin_amdgcn_readlane(ok, 0);
+        ca = readlane_d(va, 0);
+        cb = readlane_d(vb, 0);
     }
 }
 
@@ -106,13 +151,10 @@ __device__ inline void carry_down2(double (&a)[NJ], double (&b)[NJ], const bool 
 template <int NJ>
 __device__ inline void shift_from_above(const double (&s)[NJ], double (&up)[NJ])
 {
-    const int lane = lane_id();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        double u = __shfl_down(s[j], 1, WAVE);
-        double nxt = 0.;
-        if (j + 1 < NJ) nxt = __shfl(s[j + 1 < NJ ? j + 1 : j], 0, WAVE);
-        up[j] = (lane == WAVE - 1) ? nxt : u;
+        const double nxt = j + 1 < NJ ? readlane_d(s[j + 1 < NJ ? j + 1 : j], 0) : 0.;   // lane 63 <- next group
+        up[j] = dpp_d<DPP_WAVE_SHL1>(nxt, s[j]);
     }
 }
 
@@ -136,31 +178,38 @@ __device__ inline double root4(double x) { return sqrt(sqrt(x)); }              
 __device__ inline double root6(double x) { return sqrt(cbrt(x)); }                 // **(1./6.), M:1701
 
 // ---------------- scalar helpers ----------------
-// 10.**n as flang lowers real**integer (compiler-rt __powidf2), M:1766 etc.
-__device__ inline double pow10i(int b)
+// Decade index of M:1763-1771 and its seven siblings:
+//     nic = NINT(ALOG10(x));  n = first of {nic-1, nic, nic+1} with x/10.**n in [1,10);
+//     idx = INT(x/10.**n) + 10*(n-n0) - (n-n0), clamped to 1..ntb
+// where 10.**n is real**integer (compiler-rt __powidf2: the exact power 10^|n| by squaring, then a
+// reciprocal for n < 0).  Exactly one n has a mantissa in [1,10), so it is found here without the
+// log10: estimate n from the binary exponent, build 10^|n| exactly from its bits (every partial
+// product is a power of ten <= 1e22, hence exact, hence equal to __powidf2's), form the same two
+// divisions as the reference and step n if the mantissa falls outside [1,10).
+__device__ inline double pow10_abs(int m)                // 10^m for 0 <= m <= 31 (exact up to 22)
 {
-    const bool recip = b < 0;
-    double a = 10., r = 1.;
-    for (;;) {
-        if (b & 1) r *= a;
-        b /= 2;
-        if (b == 0) break;
-        a *= a;
-    }
-    return recip ? 1. / r : r;
+    double t = (m & 1) ? 10. : 1.;
+    t *= (m & 2) ? 100. : 1.;
+    t *= (m & 4) ? 1.e4 : 1.;
+    t *= (m & 8) ? 1.e8 : 1.;
+    t *= (m & 16) ? 1.e16 : 1.;
+    return t;
 }
-
-// decade search + index of M:1763-1771 and siblings
 __device__ inline int decade_idx(double x, int n0, int ntb)
 {
-    const int nic = int(lround(log10(x)));
-    int n = nic - 1;
-    for (int nn = nic - 1; nn <= nic + 1; ++nn) {
-        n = nn;
-        const double q = x / pow10i(nn);
-        if (q >= 1.0 && q < 10.0) break;
+    const int e2 = int((__double_as_longlong(x) >> 52) & 0x7ff) - 1023;
+    int n = (e2 * 1233) >> 12;                           // ~ floor(e2*log10(2)), off by at most one
+    double q = 1.;
+#pragma unroll 1
+    for (int it = 0; it < 3; ++it) {
+        const double T = pow10_abs(n < 0 ? -n : n);
+        const double P = n < 0 ? 1. / T : T;             // 10.**n
+        q = x / P;
+        if (q >= 10.0) ++n;
+        else if (q < 1.0) --n;
+        else break;
     }
-    int idx = int(x / pow10i(n)) + 10 * (n - n0) - (n - n0);
+    int idx = int(q) + 10 * (n - n0) - (n - n0);
     idx = idx < ntb ? idx : ntb;
     return idx > 1 ? idx : 1;
 }
