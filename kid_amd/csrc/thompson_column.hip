@@ -312,12 +312,13 @@ __device__ inline gdouble *uniform_ptr(const double *p)
     return (gdouble *)((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
-template <int NJ, bool RATES>
+// NJ = level groups per lane (ceil(nz/64)); NL = LDS stride per slot (>= nz), a compile-time
+// constant so that every slot address is "one VGPR (8k) + immediate offset (slot*NL*8)".
+template <int NJ, int NL, bool RATES>
 __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a)
 {
-    extern __shared__ double Ldyn[];                 // [NSLOT][lstride], lstride = nz rounded up to even
-    const int lstride = (a.nz + 1) & ~1;
-#define L(slot, k) Ldyn[(slot) * lstride + (k)]
+    __shared__ double Lsh[NSLOT * NL];               // [NSLOT][NL]
+#define L(slot, k) Lsh[(slot) * NL + (k)]
 
     const Consts &c = g_consts[a.cslot];
     const Tables &tb = a.tables;
@@ -1668,12 +1669,11 @@ hipError_t upload_consts(int slot, const Consts &c)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_consts), &c, sizeof(Consts), size_t(slot) * sizeof(Consts), hipMemcpyHostToDevice);
 }
 
-template <int NJ>
+template <int NJ, int NL>
 static hipError_t launch_nj(const StepArgs &a, bool rates, int grid, hipStream_t s)
 {
-    const size_t lds = size_t(NSLOT) * size_t((a.nz + 1) & ~1) * sizeof(double);
-    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, true>), dim3(grid), dim3(WAVE), lds, s, a);
-    else       hipLaunchKernelGGL((thompson_column_step<NJ, false>), dim3(grid), dim3(WAVE), lds, s, a);
+    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, true>), dim3(grid), dim3(WAVE), 0, s, a);
+    else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, false>), dim3(grid), dim3(WAVE), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1681,17 +1681,16 @@ hipError_t launch_column_step(const StepArgs &a, hipStream_t s)
 {
     if (a.ncol <= 0) return hipSuccess;
     if (a.nz < 2 || a.nz > 4 * WAVE) return hipErrorInvalidValue;
-    const int nj = (a.nz + WAVE - 1) / WAVE;
     int64_t maxgrid = int64_t(1) << 20;
     if (const char *e = getenv("KIDMP_GRID_CAP")) maxgrid = atoll(e) > 0 ? atoll(e) : maxgrid;   // tuning aid
     const int grid = int(a.ncol < maxgrid ? a.ncol : maxgrid);
     const bool rates = a.rates != nullptr;
-    switch (nj) {
-        case 1: return launch_nj<1>(a, rates, grid, s);
-        case 2: return launch_nj<2>(a, rates, grid, s);
-        case 3: return launch_nj<3>(a, rates, grid, s);
-        default: return launch_nj<4>(a, rates, grid, s);
-    }
+    // LDS per column = 21 slots * NL * 8 B; NL = 120 (KiD's nz) gives 8 resident columns per CU
+    if (a.nz <= 64)  return launch_nj<1, 64>(a, rates, grid, s);
+    if (a.nz <= 120) return launch_nj<2, 120>(a, rates, grid, s);
+    if (a.nz <= 128) return launch_nj<2, 128>(a, rates, grid, s);
+    if (a.nz <= 192) return launch_nj<3, 192>(a, rates, grid, s);
+    return launch_nj<4, 256>(a, rates, grid, s);
 }
 
 }  // namespace kidmp
