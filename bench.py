@@ -46,6 +46,21 @@ def make_workload(name, ncol):
     raise SystemExit("unknown workload " + name)
 
 
+def measured_traffic(workload, ncol):
+    """HBM bytes per launch of the column-step kernel from a committed rocprofv3 --pmc run of this
+    same workload (profiles/pmc_<workload>.json, made by tools/pmc_profile.sh; FETCH_SIZE and
+    WRITE_SIZE are in KiB and come from separate passes).  On gfx950 FETCH_SIZE reports half of the
+    bytes of a coalesced stream; tools/calibrate_fetch.sh measured 1/1.84 for this kernel's 8-byte-
+    per-lane loads on a known byte count, so the read side is doubled (MI355X_MICROARCH.md, HBM)."""
+    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    if int(d.get("ncol", ncol)) != ncol or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+        return None
+    return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+
+
 def cpu_baseline(model, st, iiwarm, budget_s=12.0):
     """The cpu_baseline leg: the oracle (a CPU port of the reference) on this host's cores on a
     bounded sample of the same workload, and -- with the same oracle output -- the accuracy figure
@@ -158,6 +173,7 @@ def main():
         total_cols = ncol * world
         value = total_cols * args.steps / elapsed
         achieved = ALGO_BYTES_FP64 * ncol / (kern_ms * 1e-3)
+        tbytes = measured_traffic(args.workload, ncol)
         out = {
             "metric": "thompson_mp_column_steps_per_sec", "value": value, "unit": "column-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -166,7 +182,9 @@ def main():
             "config": {"workload": desc + ", nz=120, dt=10 s, fp64", "ncol_per_gpu": ncol, "nz": NZ, "dt": DT,
                        "parallelism": "columns sharded over ranks, no halo; one RCCL all-reduce of 4 precipitation sums"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK,
+                         "traffic": None if tbytes is None else tbytes / (kern_ms * 1e-3) / 1e9,
+                         "traffic_bytes_per_launch": tbytes,
                          "kernel": ThompsonMP.kernel_name(), "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_column_step": ALGO_BYTES_FP64,
                          "note": "fp64 transcendental-bound path (SURVEY 8d): the HBM fraction is reported as "

@@ -12,6 +12,7 @@ import json
 out={}
 for x in "abcd":
     d=json.load(open("gpurun_out/pmc_$2_%s.json"%x)); out.update(d["mean"]); out["meta"]=d["meta"]; out["dispatches"]=d["dispatches"]
+out["workload"]="$1"; out["ncol"]=int(out["meta"]["Grid_Size"])//64
 json.dump(out,open("gpurun_out/pmc_$2.json","w"),indent=1)
 print(json.dumps(out))
 PY
