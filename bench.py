@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--workload", default="config2", choices=["config2", "config3", "config5"])
     ap.add_argument("--ncol", type=int, default=0, help="columns per GPU (default: the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank); gloo only to rehearse N ranks on fewer GPUs")
     args = ap.parse_args()
 
     import numpy as np
@@ -132,9 +134,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and local >= ndev:
+        raise SystemExit("rank %d needs its own GPU (found %d); use --backend gloo to rehearse" % (local, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))    # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))    # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     ncol = args.ncol or {"config2": 10000, "config3": 100000, "config5": 100000}[args.workload]
 
     st, iiwarm, desc = make_workload(args.workload, ncol)
@@ -160,11 +170,12 @@ def main():
         ev1[i].record()
     diag = model.reduce_ppt(ppt)           # domain sums of surface precipitation (W:248-275 analogue)
     if world > 1:
+        diag = diag.to(coll_dev)
         dist.all_reduce(diag)              # the only collective: final diagnostics reduction
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
