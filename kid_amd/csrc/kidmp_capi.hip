@@ -187,6 +187,10 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
         }
     }
     host_init(cfg->iiwarm ? 1 : 0, cfg->l_sediment ? 1 : 0, cfg->set_Nc, c->hc, c->hb);
+    if (!generated_consts_match(c->hc)) {
+        g_err = "kidmp_init: thompson_consts_gen.h is stale (rebuild: make -C kid_amd/csrc clean all)";
+        return bail(KIDMP_ESTATE);
+    }
     hipError_t e;
 #define INITTRY(x) do { e = (x); if (e != hipSuccess) { g_err = std::string(#x ": ") + hipGetErrorString(e); return bail(KIDMP_EHIP); } } while (0)
     INITTRY(hipStreamCreate(&c->stream));

@@ -27,6 +27,7 @@ struct StepArgs {
 
 hipError_t launch_column_step(const StepArgs &a, hipStream_t s);
 hipError_t upload_consts(int slot, const Consts &c);
+bool generated_consts_match(const Consts &c);   // thompson_consts_gen.h vs the run-time host init
 const char *column_kernel_name();
 
 }  // namespace kidmp

@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "thompson_column.h"
+#include "thompson_consts_gen.h"   // kc::*, generated at build time by gen_consts.cpp
 
 #include <cstdlib>
 
@@ -254,8 +255,8 @@ __device__ inline double fit(const double *s, double tc, double x)
 }
 __device__ inline double snow_moment(const Consts &c, double tc0, double order, double smo2)
 {
-    const double a_ = exp10(fit(c.sa, tc0, order));
-    const double b_ = fit(c.sb, tc0, order);
+    const double a_ = exp10(fit(kc::sa, tc0, order));
+    const double b_ = fit(kc::sb, tc0, order);
     return a_ * pow(smo2, b_);
 }
 
@@ -273,7 +274,7 @@ __device__ inline double graupel_N0(bool use_rain, double mvd_r, double rg)
 __device__ inline double nr_from_mvd(const Consts &c, double rr, double mvd)
 {
     const double lamr = (3.0 + mu_r + 0.672) / mvd;
-    return c.crg[1] * c.org3 * rr * cube(lamr) / am_r;
+    return kc::crg[1] * kc::org3 * rr * cube(lamr) / am_r;
 }
 
 // LDS slots ([slot][level]).  S0 = after block C, S1 = after block J, S2 = after block N.
@@ -379,17 +380,17 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 ri = qi1 * rho;
                 ni = fmax(R2, i_ni[j] * rho);
                 if (ni <= R2) {
-                    const double lami = c.cie[1] / 25.E-6;
-                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * cube(lami));
+                    const double lami = kc::cie[1] / 25.E-6;
+                    ni = fmin(499.e3, kc::cig[0] * kc::oig2 * ri / am_i * cube(lami));
                 }
-                double lami = root3(am_i * c.cig[1] * c.oig1 * ni / ri);
+                double lami = root3(am_i * kc::cig[1] * kc::oig1 * ni / ri);
                 const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
                 if (xDi < 5.E-6) {
-                    lami = c.cie[1] / 5.E-6;
-                    ni = fmin(499.e3, c.cig[0] * c.oig2 * ri / am_i * cube(lami));
+                    lami = kc::cie[1] / 5.E-6;
+                    ni = fmin(499.e3, kc::cig[0] * kc::oig2 * ri / am_i * cube(lami));
                 } else if (xDi > 300.E-6) {
-                    lami = c.cie[1] / 300.E-6;
-                    ni = c.cig[0] * c.oig2 * ri / am_i * cube(lami);
+                    lami = kc::cie[1] / 300.E-6;
+                    ni = kc::cig[0] * kc::oig2 * ri / am_i * cube(lami);
                 }
             }
             if (qr1 > R1) {                                  // M:1447-1474
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 rr = qr1 * rho;
                 nr = fmax(R2, i_nr[j] * rho);
                 if (nr <= R2) nr = nr_from_mvd(c, rr, 1.0E-3);
-                const double lamr = root3(am_r * c.crg[2] * c.org2 * nr / rr);
+                const double lamr = root3(am_r * kc::crg[2] * kc::org2 * nr / rr);
                 double mvd = (3.0 + mu_r + 0.672) / lamr;
                 if (mvd > 2.5E-3) {
                     mvd = 2.5E-3;
@@ -505,33 +506,33 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             double smob = 0., smo0 = 0., smo1 = 0., smoc = 0., smoe = 0., smof = 0.;
             if (!iiwarm && L_qs) {
                 const double tc0 = fmin(-0.1, temp - 273.15);
-                smob = rs * c.oams;
+                smob = rs * kc::oams;
                 const double smo2 = smob;                    // bm_s == 2 (M:1553-1554)
                 {   // 0th moment, M:1571-1574
-                    const double la = c.sa[0] + c.sa[1] * tc0 + c.sa[4] * tc0 * tc0 + c.sa[8] * tc0 * tc0 * tc0;
-                    const double b_ = c.sb[0] + c.sb[1] * tc0 + c.sb[4] * tc0 * tc0 + c.sb[8] * tc0 * tc0 * tc0;
+                    const double la = kc::sa[0] + kc::sa[1] * tc0 + kc::sa[4] * tc0 * tc0 + kc::sa[8] * tc0 * tc0 * tc0;
+                    const double b_ = kc::sb[0] + kc::sb[1] * tc0 + kc::sb[4] * tc0 * tc0 + kc::sb[8] * tc0 * tc0 * tc0;
                     smo0 = exp10(la) * pow(smo2, b_);
                 }
                 {   // 1st moment, M:1577-1587
-                    const double la = c.sa[0] + c.sa[1] * tc0 + c.sa[2] + c.sa[3] * tc0 + c.sa[4] * tc0 * tc0 + c.sa[5]
-                                    + c.sa[6] * tc0 * tc0 + c.sa[7] * tc0 + c.sa[8] * tc0 * tc0 * tc0 + c.sa[9];
-                    const double b_ = c.sb[0] + c.sb[1] * tc0 + c.sb[2] + c.sb[3] * tc0 + c.sb[4] * tc0 * tc0 + c.sb[5]
-                                    + c.sb[6] * tc0 * tc0 + c.sb[7] * tc0 + c.sb[8] * tc0 * tc0 * tc0 + c.sb[9];
+                    const double la = kc::sa[0] + kc::sa[1] * tc0 + kc::sa[2] + kc::sa[3] * tc0 + kc::sa[4] * tc0 * tc0 + kc::sa[5]
+                                    + kc::sa[6] * tc0 * tc0 + kc::sa[7] * tc0 + kc::sa[8] * tc0 * tc0 * tc0 + kc::sa[9];
+                    const double b_ = kc::sb[0] + kc::sb[1] * tc0 + kc::sb[2] + kc::sb[3] * tc0 + kc::sb[4] * tc0 * tc0 + kc::sb[5]
+                                    + kc::sb[6] * tc0 * tc0 + kc::sb[7] * tc0 + kc::sb[8] * tc0 * tc0 * tc0 + kc::sb[9];
                     smo1 = exp10(la) * pow(smo2, b_);
                 }
-                smoc = snow_moment(c, tc0, c.cse[0], smo2);  // M:1590-1600
-                smoe = snow_moment(c, tc0, c.cse[12], smo2); // M:1603-1613
-                smof = snow_moment(c, tc0, c.cse[15], smo2); // M:1616-1626
+                smoc = snow_moment(c, tc0, kc::cse[0], smo2);  // M:1590-1600
+                smoe = snow_moment(c, tc0, kc::cse[12], smo2); // M:1603-1613
+                smof = snow_moment(c, tc0, kc::cse[15], smo2); // M:1616-1626
             }
 
             // ---- E (per level part): graupel slope/intercept, M:1650-1653 ----
             double ilamg = 0., N0_g = 0., ig_bv = 0., ig11 = 0.;
             if (!iiwarm) {
                 const double N0_exp = L(V_N0X, k);
-                const double lam_exp = root4(N0_exp * am_g * c.cgg[0] / rg);
-                const double lamg = lam_exp * c.lamg_fac;
+                const double lam_exp = root4(N0_exp * am_g * kc::cgg[0] / rg);
+                const double lamg = lam_exp * kc::lamg_fac;
                 ilamg = 1. / lamg;
-                N0_g = N0_exp / (c.cgg[1] * lam_exp) * lamg;          // lamg**cge(2), cge(2) = 1
+                N0_g = N0_exp / (kc::cgg[1] * lam_exp) * lamg;          // lamg**cge(2), cge(2) = 1
                 if (L_qg) {
                     // ilamg**bv_g is the one general power; cge(9) = 3 + bv_g, cge(10) = 2, cge(11) = 2.5 + bv_g/2
                     ig_bv = pow(ilamg, bv_g);
@@ -540,10 +541,10 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             }
 
             // ---- F: rain slope/intercept, M:1661-1666 ----
-            const double lamr0 = root3(am_r * c.crg[2] * c.org2 * nr / rr);
+            const double lamr0 = root3(am_r * kc::crg[2] * kc::org2 * nr / rr);
             const double ilamr = 1. / lamr0;
             double mvd_r = (3.0 + mu_r + 0.672) / lamr0;
-            const double N0_r = nr * c.org2 * lamr0;                // lamr**cre(2), cre(2) = 1
+            const double N0_r = nr * kc::org2 * lamr0;                // lamr**cre(2), cre(2) = 1
             const double lamr = 1. / ilamr;                  // "lamr = 1./ilamr(k)", M:1716 ...
 
             // all process rates start at zero, M:1282-1363
@@ -596,16 +597,16 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 nc_m += pnc_wau;
             }
             if (L_qr && mvd_r > D0r && mvd_c > D0c) {        // accretion, M:1715-1726
-                int idx = 1 + int(nbins * log(mvd_r / c.Dr1) / log(c.Drn / c.Dr1));
+                int idx = 1 + int(nbins * log(mvd_r / kc::Dr1) / log(kc::Drn / kc::Dr1));
                 idx = idx < nbins ? idx : nbins;
                 idx = idx > 1 ? idx : 1;
                 int jc = int(mvd_c * 1.E6);
                 jc = jc < 1 ? 1 : (jc > nbins ? nbins : jc);
                 const double Ef_rw = tb.t_Efrw[(idx - 1) + nbins * (jc - 1)];
                 const double coll = 1. / pw4(lamr + fv_r);               // (lamr+fv_r)**(-cre(9)), cre(9) = 4
-                prr_rcw = rhof * c.t1_qr_qc * Ef_rw * rc * N0_r * coll;
+                prr_rcw = rhof * kc::t1_qr_qc * Ef_rw * rc * N0_r * coll;
                 prr_rcw = fmin(rc * odts, prr_rcw);
-                pnc_rcw = rhof * c.t1_qr_qc * Ef_rw * nc * N0_r * coll;
+                pnc_rcw = rhof * kc::t1_qr_qc * Ef_rw * nc * N0_r * coll;
                 pnc_rcw = fmin(nc * odts, pnc_rcw);
                 nc_m += pnc_rcw;
             }
@@ -621,24 +622,24 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 idx_t = 1 > -idx_t ? 1 : -idx_t;
                 idx_t = idx_t < ntb_t ? idx_t : ntb_t;
 
-                const int idx_c = rc > c.r_c1 ? decade_idx(rc, c.nic2, ntb_c) : 1;
-                const int idx_i = ri > c.r_i1 ? decade_idx(ri, c.nii2, ntb_i) : 1;
-                const int idx_i1 = ni > c.Nt_i1 ? decade_idx(ni, c.nii3, ntb_i1) : 1;
+                const int idx_c = rc > kc::r_c1 ? decade_idx(rc, kc::nic2, ntb_c) : 1;
+                const int idx_i = ri > kc::r_i1 ? decade_idx(ri, kc::nii2, ntb_i) : 1;
+                const int idx_i1 = ni > kc::Nt_i1 ? decade_idx(ni, kc::nii3, ntb_i1) : 1;
                 int idx_r = 1, idx_r1 = ntb_r1;
-                if (rr > c.r_r1) {
-                    idx_r = decade_idx(rr, c.nir2, ntb_r);
-                    const double lam_exp = lamr * c.lamr_exp_fac;
-                    const double N0_exp = c.org1 * rr / am_r * pw4(lam_exp);   // **cre(1) = 4
-                    idx_r1 = decade_idx(N0_exp, c.nir3, ntb_r1);
+                if (rr > kc::r_r1) {
+                    idx_r = decade_idx(rr, kc::nir2, ntb_r);
+                    const double lam_exp = lamr * kc::lamr_exp_fac;
+                    const double N0_exp = kc::org1 * rr / am_r * pw4(lam_exp);   // **cre(1) = 4
+                    idx_r1 = decade_idx(N0_exp, kc::nir3, ntb_r1);
                 }
-                const int idx_s = rs > c.r_s1 ? decade_idx(rs, c.nis2, ntb_s) : 1;
+                const int idx_s = rs > kc::r_s1 ? decade_idx(rs, kc::nis2, ntb_s) : 1;
                 int idx_g = 1, idx_g1 = ntb_g1;
-                if (rg > c.r_g1) {
-                    idx_g = decade_idx(rg, c.nig2, ntb_g);
+                if (rg > kc::r_g1) {
+                    idx_g = decade_idx(rg, kc::nig2, ntb_g);
                     const double lamg = 1. / ilamg;
-                    const double lam_exp = lamg * c.lamg_exp_fac;
-                    const double N0_exp = c.ogg1 * rg / am_g * pw4(lam_exp);   // **cge(1) = 4
-                    idx_g1 = decade_idx(N0_exp, c.nig3, ntb_g1);
+                    const double lam_exp = lamg * kc::lamg_exp_fac;
+                    const double N0_exp = kc::ogg1 * rg / am_g * pw4(lam_exp);   // **cge(1) = 4
+                    idx_g1 = decade_idx(N0_exp, kc::nig3, ntb_g1);
                 }
 
                 // Srivastava & Coen prefactor over ice, M:1884-1900
@@ -661,18 +662,18 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     int jc = int(mvd_c * 1.E6);
                     jc = jc < 1 ? 1 : (jc > nbins ? nbins : jc);
                     if (xDs > D0s) {
-                        int idx = 1 + int(nbins * log(xDs / c.Ds1) / log(c.Dsn / c.Ds1));
+                        int idx = 1 + int(nbins * log(xDs / kc::Ds1) / log(kc::Dsn / kc::Ds1));
                         idx = idx < nbins ? idx : nbins;
                         idx = idx > 1 ? idx : 1;
                         const double Ef_sw = tb.t_Efsw[(idx - 1) + nbins * (jc - 1)];
-                        prs_scw = rhof * c.t1_qs_qc * Ef_sw * rc * smoe;
-                        pnc_scw = rhof * c.t1_qs_qc * Ef_sw * nc * smoe;
+                        prs_scw = rhof * kc::t1_qs_qc * Ef_sw * rc * smoe;
+                        pnc_scw = rhof * kc::t1_qs_qc * Ef_sw * nc * smoe;
                         pnc_scw = fmin(nc * odts, pnc_scw);
                         nc_m += pnc_scw;
                     }
-                    if (rg >= c.r_g1 && mvd_c > D0c) {
+                    if (rg >= kc::r_g1 && mvd_c > D0c) {
                         const double xDg = (bm_g + mu_g + 1.) * ilamg;
-                        const double vtg = rhof * av_g * c.cgg[5] * c.ogg3 * ig_bv;
+                        const double vtg = rhof * av_g * kc::cgg[5] * kc::ogg3 * ig_bv;
                         const double stoke_g = mvd_c * mvd_c * vtg * rho_w / (9. * visco * xDg);
                         if (xDg > D0g) {
                             double Ef_gw = 0.;
@@ -680,8 +681,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                             else if (stoke_g < 0.4)               Ef_gw = 0.0;
                             else if (stoke_g > 10)                Ef_gw = 0.77;
                             const double ig9 = cube(ilamg) * ig_bv;          // ilamg**cge(9), cge(9) = 3 + bv_g
-                            prg_gcw = rhof * c.t1_qg_qc * Ef_gw * rc * N0_g * ig9;
-                            pnc_gcw = rhof * c.t1_qg_qc * Ef_gw * nc * N0_g * ig9;
+                            prg_gcw = rhof * kc::t1_qg_qc * Ef_gw * rc * N0_g * ig9;
+                            pnc_gcw = rhof * kc::t1_qg_qc * Ef_gw * nc * N0_g * ig9;
                             pnc_gcw = fmin(nc * odts, pnc_gcw);
                             nc_m += pnc_gcw;
                         }
@@ -689,8 +690,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 }
 
                 // rain <-> snow / graupel collection from the tables, M:1964-2019
-                if (rr >= c.r_r1) {
-                    if (rs >= c.r_s1) {
+                if (rr >= kc::r_r1) {
+                    if (rs >= kc::r_s1) {
                         const int64_t id = (idx_s - 1) + int64_t(ntb_s) * ((idx_t - 1) + int64_t(ntb_t) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_r - 1)));
                         const double *r = tb.racs_rec + id * RACS_REC;
                         const double tmr_racs1 = r[0], tcr_sacr1 = r[1], tmr_racs2 = r[2], tcr_sacr2 = r[3],
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         pnr_rcs = fmin(nr * odts, pnr_rcs);
                         nr_m += pnr_rcs;
                     }
-                    if (rg >= c.r_g1) {
+                    if (rg >= kc::r_g1) {
                         const int64_t id = (idx_g1 - 1) + int64_t(ntb_g1) * ((idx_g - 1) + int64_t(ntb_g) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_r - 1)));
                         const double *r = tb.racg_rec + id * RACG_REC;
                         if (temp < T_0) {
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     vts_boost = 1.0;
                     const double rate_max = (qv - qvsi) * rho * odts * 0.999;
 
-                    if (rr > c.r_r1) {                       // Bigg freezing, M:2066-2086
+                    if (rr > kc::r_r1) {                       // Bigg freezing, M:2066-2086
                         const int64_t id = (idx_r - 1) + int64_t(ntb_r) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_tc - 1));
                         const double *r = tb.qrfz_rec + id * QRFZ_REC;
                         prg_rfz = r[0] * odts;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         nr_m += pnr_rfz;
                         ni_p += pni_rfz;
                     }
-                    if (rc > c.r_c1) {
+                    if (rc > kc::r_c1) {
                         const int id = (idx_c - 1) + ntb_c * (idx_tc - 1);
                         pri_wfz = tb.tpi_qcfz[id] * odts;
                         pri_wfz = fmin(rc * odts, pri_wfz);
@@ -778,12 +779,12 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     }
 
                     if (L_qi) {                              // M:2116-2149 and M:2178-2202
-                        const double lami = root3(am_i * c.cig[1] * c.oig1 * ni / ri);
+                        const double lami = root3(am_i * kc::cig[1] * kc::oig1 * ni / ri);
                         const double ilami = 1. / lami;
-                        const double xDi = fmax(c.D0i, (bm_i + mu_i + 1.) * ilami);
+                        const double xDi = fmax(kc::D0i, (bm_i + mu_i + 1.) * ilami);
                         const double xmi = am_i * cube(xDi);
                         const double oxmi = 1. / xmi;
-                        pri_ide = C_cube * t1_subl * diffu * ssati * rvs * c.oig1 * c.cig[4] * ni * ilami;
+                        pri_ide = C_cube * t1_subl * diffu * ssati * rvs * kc::oig1 * kc::cig[4] * ni * ilami;
                         const int id = (idx_i - 1) + ntb_i * (idx_i1 - 1);
                         if (pri_ide < 0.0) {
                             pri_ide = fmax(fmax(-ri * odts, pri_ide), rate_max);
@@ -808,19 +809,19 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                             pni_iau = fmin(ni * .95 * odts, pni_iau);
                         }
                         ni_m += pni_iau;
-                        if (rs >= c.r_s1) {
-                            prs_sci = c.t1_qs_qi * rhof * Ef_si * ri * smoe;
+                        if (rs >= kc::r_s1) {
+                            prs_sci = kc::t1_qs_qi * rhof * Ef_si * ri * smoe;
                             pni_sci = prs_sci * oxmi;
                             ni_m += pni_sci;
                         }
-                        if (rr >= c.r_r1 && mvd_r > 4. * xDi) {
+                        if (rr >= kc::r_r1 && mvd_r > 4. * xDi) {
                             const double c9 = 1. / pw4(lamr + fv_r);
-                            pri_rci = rhof * c.t1_qr_qi * Ef_ri * ri * N0_r * c9;
-                            pnr_rci = rhof * c.t1_qr_qi * Ef_ri * ni * N0_r * c9;
+                            pri_rci = rhof * kc::t1_qr_qi * Ef_ri * ri * N0_r * c9;
+                            pnr_rci = rhof * kc::t1_qr_qi * Ef_ri * ni * N0_r * c9;
                             pni_rci = pri_rci * oxmi;
                             ni_m += pni_rci;
                             nr_m += pnr_rci;
-                            prr_rci = rhof * c.t2_qr_qi * Ef_ri * ni * N0_r * (1. / pw7(lamr + fv_r));   // **(-cre(8)), cre(8) = 7
+                            prr_rci = rhof * kc::t2_qr_qi * Ef_ri * ni * N0_r * (1. / pw7(lamr + fv_r));   // **(-cre(8)), cre(8) = 7
                             prr_rci = fmin(rr * odts, prr_rci);
                             prg_rci = pri_rci + prr_rci;
                         }
@@ -829,13 +830,13 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     if (L_qs) {                              // snow deposition, M:2153-2164
                         double C_snow = C_sqrd + (tempc + 1.5) * (C_cube - C_sqrd) / (-30. + 1.5);
                         C_snow = fmax(C_sqrd, fmin(C_snow, C_cube));
-                        prs_sde = C_snow * t1_subl * diffu * ssati * rvs * (c.t1_qs_sd * smo1 + c.t2_qs_sd * rhof2 * vsc2 * smof);
+                        prs_sde = C_snow * t1_subl * diffu * ssati * rvs * (kc::t1_qs_sd * smo1 + kc::t2_qs_sd * rhof2 * vsc2 * smof);
                         if (prs_sde < 0.) prs_sde = fmax(fmax(-rs * odts, prs_sde), rate_max);
                         else              prs_sde = fmin(prs_sde, rate_max);
                     }
                     if (L_qg && ssati < -eps) {              // graupel sublimation, M:2166-2175
                         prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g
-                                * (c.t1_qg_sd * (ilamg * ilamg) + c.t2_qg_sd * vsc2 * rhof2 * ig11);
+                                * (kc::t1_qg_sd * (ilamg * ilamg) + kc::t2_qg_sd * vsc2 * rhof2 * ig11);
                         if (prg_gde < 0.) prg_gde = fmax(fmax(-rg * odts, prg_gde), rate_max);
                         else              prg_gde = fmin(prg_gde, rate_max);
                     }
@@ -859,25 +860,25 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     }
                 } else {                                     // ---- melting, M:2237-2281 ----
                     if (L_qs) {
-                        prr_sml = (tempc * tcond - lvap0 * diffu * delQvs) * (c.t1_qs_me * smo1 + c.t2_qs_me * rhof2 * vsc2 * smof);
+                        prr_sml = (tempc * tcond - lvap0 * diffu * delQvs) * (kc::t1_qs_me * smo1 + kc::t2_qs_me * rhof2 * vsc2 * smof);
                         prr_sml = prr_sml + 4218. * olfus * tempc * (prr_rcs + prs_scw);
                         prr_sml = fmin(rs * odts, fmax(0., prr_sml));
                         pnr_sml = smo0 / rs * prr_sml * exp10(-0.25 * tempc);
                         pnr_sml = fmin(smo0 * odts, pnr_sml);
                         nr_p += pnr_sml;
                         if (ssati < 0.) {
-                            prs_sde = C_cube * t1_subl * diffu * ssati * rvs * (c.t1_qs_sd * smo1 + c.t2_qs_sd * rhof2 * vsc2 * smof);
+                            prs_sde = C_cube * t1_subl * diffu * ssati * rvs * (kc::t1_qs_sd * smo1 + kc::t2_qs_sd * rhof2 * vsc2 * smof);
                             prs_sde = fmax(-rs * odts, prs_sde);
                         }
                     }
                     if (L_qg) {
                         const double ig10 = ilamg * ilamg;
-                        prr_gml = (tempc * tcond - lvap0 * diffu * delQvs) * N0_g * (c.t1_qg_me * ig10 + c.t2_qg_me * rhof2 * vsc2 * ig11);
+                        prr_gml = (tempc * tcond - lvap0 * diffu * delQvs) * N0_g * (kc::t1_qg_me * ig10 + kc::t2_qg_me * rhof2 * vsc2 * ig11);
                         prr_gml = fmin(rg * odts, fmax(0., prr_gml));
-                        pnr_gml = N0_g * c.cgg[1] * ilamg / rg * prr_gml * exp10(-0.5 * tempc);
+                        pnr_gml = N0_g * kc::cgg[1] * ilamg / rg * prr_gml * exp10(-0.5 * tempc);
                         nr_p += pnr_gml;
                         if (ssati < 0.) {
-                            prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g * (c.t1_qg_sd * ig10 + c.t2_qg_sd * vsc2 * rhof2 * ig11);
+                            prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g * (kc::t1_qg_sd * ig10 + kc::t2_qg_sd * vsc2 * rhof2 * ig11);
                             prg_gde = fmax(-rg * odts, prg_gde);
                         }
                     }
@@ -983,15 +984,15 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 const double xri = fmax(R1, (qi1 + qiten * DT) * rho);
                 double xni = fmax(R2, (ni1 + niten * DT) * rho);
                 if (xri > R1) {
-                    double lami = root3(am_i * c.cig[1] * c.oig1 * xni / xri);
+                    double lami = root3(am_i * kc::cig[1] * kc::oig1 * xni / xri);
                     const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
                     if (xDi < 5.E-6) {
-                        lami = c.cie[1] / 5.E-6;
-                        xni = fmin(499.e3, c.cig[0] * c.oig2 * xri / am_i * cube(lami));
+                        lami = kc::cie[1] / 5.E-6;
+                        xni = fmin(499.e3, kc::cig[0] * kc::oig2 * xri / am_i * cube(lami));
                         niten = (xni - ni1 * rho) * odts * orho;
                     } else if (xDi > 300.E-6) {
-                        lami = c.cie[1] / 300.E-6;
-                        xni = c.cig[0] * c.oig2 * xri / am_i * cube(lami);
+                        lami = kc::cie[1] / 300.E-6;
+                        xni = kc::cig[0] * kc::oig2 * xri / am_i * cube(lami);
                         niten = (xni - ni1 * rho) * odts * orho;
                     }
                 } else {
@@ -1007,7 +1008,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 const double xrr = fmax(R1, (qr1 + qrten * DT) * rho);
                 double xnr = fmax(R2, (nr1 + nrten * DT) * rho);
                 if (xrr > R1) {
-                    const double lr = root3(am_r * c.crg[2] * c.org2 * xnr / xrr);
+                    const double lr = root3(am_r * kc::crg[2] * kc::org2 * xnr / xrr);
                     mvd_r = (3.0 + mu_r + 0.672) / lr;
                     if (mvd_r > 2.5E-3) {
                         xnr = nr_from_mvd(c, xrr, 2.5E-3);
@@ -1107,7 +1108,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 rr = (qr1 + qrten * DT) * rho;
                 nr = fmax(R2, (nr1 + nrten * DT) * rho);
                 f2 |= F_QR;
-                const double lr = root3(am_r * c.crg[2] * c.org2 * nr / rr);
+                const double lr = root3(am_r * kc::crg[2] * kc::org2 * nr / rr);
                 double mvd = (3.0 + mu_r + 0.672) / lr;
                 if (mvd > 2.5E-3)           { mvd = 2.5E-3;      nr = nr_from_mvd(c, rr, mvd); }
                 else if (mvd < D0r * 0.75)  { mvd = D0r * 0.75;  nr = nr_from_mvd(c, rr, mvd); }
@@ -1122,15 +1123,15 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             double xDs = 0.;
             if (!iiwarm && (f2 & F_QS)) {
                 const double tc0 = fmin(-0.1, temp - 273.15);
-                const double smob = rs * c.oams;
-                const double smoc = snow_moment(c, tc0, c.cse[0], smob);
+                const double smob = rs * kc::oams;
+                const double smoc = snow_moment(c, tc0, kc::cse[0], smob);
                 xDs = smoc / smob;                           // smod (M:2701-2711) feeds nothing
             }
 
             // rain PSD, M:2745-2750
-            const double lamrK = root3(am_r * c.crg[2] * c.org2 * nr / rr);
+            const double lamrK = root3(am_r * kc::crg[2] * kc::org2 * nr / rr);
             const double ilamr = 1. / lamrK;
-            const double N0_r = nr * c.org2 * lamrK;                 // **cre(2) = 1
+            const double N0_r = nr * kc::org2 * lamrK;                 // **cre(2) = 1
 
             // ---- M: saturation adjustment, M:2780-2873 ----
             double orho = 1. / rho;
@@ -1198,7 +1199,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     prv_rev = rr * orho * odts;
                 } else {
                     prv_rev = t1_evap * diffu * (-ssatw) * N0_r * rvs
-                            * (c.t1_qr_ev * (ilamr * ilamr) + c.t2_qr_ev * vsc2 * rhof2 * (1. / cube(lamr + 0.5 * fv_r)));   // cre(10)=2, cre(11)=3
+                            * (kc::t1_qr_ev * (ilamr * ilamr) + kc::t2_qr_ev * vsc2 * rhof2 * (1. / cube(lamr + 0.5 * fv_r)));   // cre(10)=2, cre(11)=3
                     const double rate_max = fmin((rr * orho * odts), (qvs - qv) * odts);
                     prv_rev = fmin(rate_max, prv_rev * orho);
                     if (prr_gml > 0.0) {
@@ -1260,9 +1261,9 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 ok[j] = true;
                 const double rhof = sqrt(rho_not / rho);
                 const double nr = L(V_NR2, k);
-                const double lamr = root3(am_r * c.crg[2] * c.org2 * nr / rr);
-                vtr[j] = rhof * av_r * c.crg[5] * c.org3 * pw4(lamr) * (1. / pw5(lamr + fv_r));          // cre(3)=4, cre(6)=5
-                vtnr[j] = rhof * av_r * c.crg[6] / c.crg[11] * pw2h(lamr) * (1. / pw3h(lamr + fv_r));   // cre(12)=2.5, cre(7)=3.5
+                const double lamr = root3(am_r * kc::crg[2] * kc::org2 * nr / rr);
+                vtr[j] = rhof * av_r * kc::crg[5] * kc::org3 * pw4(lamr) * (1. / pw5(lamr + fv_r));          // cre(3)=4, cre(6)=5
+                vtnr[j] = rhof * av_r * kc::crg[6] / kc::crg[11] * pw2h(lamr) * (1. / pw3h(lamr + fv_r));   // cre(12)=2.5, cre(7)=3.5
             }
         }
         carry_down2<NJ>(vtr, vtnr, ok);
@@ -1321,11 +1322,11 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 if (ri > R1) {
                     ok[j] = true;
                     const double rhof = sqrt(rho_not / L(V_RHO2, k));
-                    const double lami = root3(am_i * c.cig[1] * c.oig1 * L(V_NI2, k) / ri);
+                    const double lami = root3(am_i * kc::cig[1] * kc::oig1 * L(V_NI2, k) / ri);
                     const double ilami = 1. / lami;
                     const double pw = ilami;                             // ilami**bv_i, bv_i = 1
-                    vti[j] = rhof * av_i * c.cig[2] * c.oig2 * pw;
-                    vtni[j] = rhof * av_i * c.cig[5] / c.cig[6] * pw;
+                    vti[j] = rhof * av_i * kc::cig[2] * kc::oig2 * pw;
+                    vtni[j] = rhof * av_i * kc::cig[5] / kc::cig[6] * pw;
                 }
             }
             carry_down2<NJ>(vti, vtni, ok);
@@ -1361,12 +1362,12 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     double ils1 = 1. / (Mrat * Lam0 + fv_s);
                     double ils2 = 1. / (Mrat * Lam1 + fv_s);
                     const double mm = pow(Mrat, mu_s);
-                    const double t1_vts = Kap0 * c.csg[3] * pow(ils1, c.cse[3]);
-                    const double t2_vts = Kap1 * mm * c.csg[9] * pow(ils2, c.cse[9]);
+                    const double t1_vts = Kap0 * kc::csg[3] * pow(ils1, kc::cse[3]);
+                    const double t2_vts = Kap1 * mm * kc::csg[9] * pow(ils2, kc::cse[9]);
                     ils1 = 1. / (Mrat * Lam0);
                     ils2 = 1. / (Mrat * Lam1);
-                    const double t3_vts = Kap0 * c.csg[0] * cube(ils1);          // **cse(1), cse(1) = bm_s+1 = 3
-                    const double t4_vts = Kap1 * mm * c.csg[6] * pow(ils2, c.cse[6]);
+                    const double t3_vts = Kap0 * kc::csg[0] * cube(ils1);          // **cse(1), cse(1) = bm_s+1 = 3
+                    const double t4_vts = Kap1 * mm * kc::csg[6] * pow(ils2, kc::cse[6]);
                     const double v = rhof * av_s * (t1_vts + t2_vts) / (t3_vts + t4_vts);
                     const double boost = L(V_BOOST, k);
                     if (tmp2[j] > (T_0 + 0.1))
@@ -1404,10 +1405,10 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     ok[j] = true;
                     const double rhof = sqrt(rho_not / L(V_RHO2, k));
                     const double N0_exp = n0x2[j];
-                    const double lam_exp = root4(N0_exp * am_g * c.cgg[0] / rg);
-                    const double lamg = lam_exp * c.lamg_fac;
+                    const double lam_exp = root4(N0_exp * am_g * kc::cgg[0] / rg);
+                    const double lamg = lam_exp * kc::lamg_fac;
                     const double ilamg = 1. / lamg;
-                    const double v = rhof * av_g * c.cgg[5] * c.ogg3 * pow(ilamg, bv_g);
+                    const double v = rhof * av_g * kc::cgg[5] * kc::ogg3 * pow(ilamg, bv_g);
                     vtg[j] = tmp2[j] > T_0 ? fmax(v, vtr[j]) : v;
                 }
             }
@@ -1628,11 +1629,11 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 qi = 0.0;
                 nin = 0.0;
             } else {
-                double lami = root3(am_i * c.cig[1] * c.oig1 * nin / qi);
+                double lami = root3(am_i * kc::cig[1] * kc::oig1 * nin / qi);
                 const double xDi = (bm_i + mu_i + 1.) * (1. / lami);
-                if (xDi < 5.E-6)          lami = c.cie[1] / 5.E-6;
-                else if (xDi > 300.E-6)   lami = c.cie[1] / 300.E-6;
-                nin = fmin(c.cig[0] * c.oig2 * qi / am_i * cube(lami), 499.e3 / rho);
+                if (xDi < 5.E-6)          lami = kc::cie[1] / 5.E-6;
+                else if (xDi > 300.E-6)   lami = kc::cie[1] / 300.E-6;
+                nin = fmin(kc::cig[0] * kc::oig2 * qi / am_i * cube(lami), 499.e3 / rho);
             }
             gqi[k] = qi;
             gni[k] = nin;
@@ -1643,7 +1644,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 qr = 0.0;
                 nrn = 0.0;
             } else {
-                const double lr = root3(am_r * c.crg[2] * c.org2 * nrn / qr);
+                const double lr = root3(am_r * kc::crg[2] * kc::org2 * nrn / qr);
                 double mvd = (3.0 + mu_r + 0.672) / lr;
                 if (mvd > 2.5E-3)           mvd = 2.5E-3;
                 else if (mvd < D0r * 0.75)  mvd = D0r * 0.75;
@@ -1662,6 +1663,30 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 }
 
 const char *column_kernel_name() { return "thompson_column_step"; }
+
+// The kernel uses the PARAMETER-derived constants as immediates from the generated header; check that
+// the header was generated from the same host code that computed `c` (bitwise).
+bool generated_consts_match(const Consts &c)
+{
+    auto same = [](const double *a, const double *b, int n) {
+        for (int i = 0; i < n; ++i)
+            if (!(a[i] == b[i])) return false;
+        return true;
+    };
+    return same(c.cie, kc::cie, 7) && same(c.cig, kc::cig, 7) && same(c.cre, kc::cre, 13) && same(c.crg, kc::crg, 13)
+        && same(c.cse, kc::cse, 18) && same(c.csg, kc::csg, 18) && same(c.cge, kc::cge, 12) && same(c.cgg, kc::cgg, 12)
+        && same(c.sa, kc::sa, 10) && same(c.sb, kc::sb, 10) && c.D0i == kc::D0i && c.oig1 == kc::oig1
+        && c.oig2 == kc::oig2 && c.org1 == kc::org1 && c.org2 == kc::org2 && c.org3 == kc::org3 && c.oams == kc::oams
+        && c.ogg1 == kc::ogg1 && c.ogg3 == kc::ogg3 && c.t1_qr_qc == kc::t1_qr_qc && c.t2_qr_qi == kc::t2_qr_qi
+        && c.t1_qg_qc == kc::t1_qg_qc && c.t2_qr_ev == kc::t2_qr_ev && c.t2_qs_sd == kc::t2_qs_sd
+        && c.t2_qs_me == kc::t2_qs_me && c.t2_qg_sd == kc::t2_qg_sd && c.t2_qg_me == kc::t2_qg_me
+        && c.t1_qs_me == kc::t1_qs_me && c.t1_qg_me == kc::t1_qg_me && c.t1_qg_sd == kc::t1_qg_sd
+        && c.lamg_fac == kc::lamg_fac && c.lamr_exp_fac == kc::lamr_exp_fac && c.lamg_exp_fac == kc::lamg_exp_fac
+        && c.Dr1 == kc::Dr1 && c.Drn == kc::Drn && c.Ds1 == kc::Ds1 && c.Dsn == kc::Dsn && c.r_c1 == kc::r_c1
+        && c.r_i1 == kc::r_i1 && c.r_r1 == kc::r_r1 && c.r_s1 == kc::r_s1 && c.r_g1 == kc::r_g1 && c.Nt_i1 == kc::Nt_i1
+        && c.nic2 == kc::nic2 && c.nii2 == kc::nii2 && c.nii3 == kc::nii3 && c.nir2 == kc::nir2 && c.nir3 == kc::nir3
+        && c.nis2 == kc::nis2 && c.nig2 == kc::nig2 && c.nig3 == kc::nig3;
+}
 
 hipError_t upload_consts(int slot, const Consts &c)
 {
