@@ -110,7 +110,7 @@ __device__ inline void suffix_min(double (&x)[NJ])
 // a[j], b[j] <- value at the nearest level at or above that has ok, else 0
 // (the "vtXk(k) = vtXk(k+1)" carry of M:3235, 3267, 3307, 3333)
 template <int NJ>
-__device__ inline void carry_down2(double (&a)[NJ], double (&b)[NJ], const bool (&okin)[NJ])
+__device__ inline void carry_down2(double (&a)[NJ], double (&b)[NJ], const int (&okin)[NJ])
 {
     const int row = lane_id() >> 4;
     double ca = 0., cb = 0.;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         // ============ pass 0: blocks B + C, M:1387-1533 ============
         int flg[NJ];
         double mvdB[NJ], rgB[NJ];
-        bool warmlev[NJ];
+        int warmlev[NJ];
         bool any_micro = false;
         // all first-touch HBM loads of the column are issued together (one round trip):
         double i_t[NJ], i_qv[NJ], i_p[NJ], i_qc[NJ], i_qi[NJ], i_qr[NJ], i_qs[NJ], i_qg[NJ], i_ni[NJ], i_nr[NJ];
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-            flg[j] = 0; mvdB[j] = 0.; rgB[j] = R1; warmlev[j] = false;
+            flg[j] = 0; mvdB[j] = 0.; rgB[j] = R1; warmlev[j] = 0;
             if (k >= nzu) continue;
             const double temp = i_t[j];
             const double qv = fmax(1.E-10, i_qv[j]);
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             if (fabs(ssatw) < eps) ssatw = 0.0;
             if (fabs(ssati) < eps) ssati = 0.0;
             if (f != 0 || ssati > 0.0) any_micro = true;
-            warmlev[j] = temp >= 270.65;
+            warmlev[j] = temp >= 270.65 ? 1 : 0;
             flg[j] = f;
 
             L(V_TEMP, k) = temp;  L(V_QV, k) = qv;    L(V_RHO, k) = rho;
@@ -1063,14 +1063,16 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 #pragma unroll 1
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-            flg2[j] = 0; mvdK[j] = 0.; warmlev[j] = false;
+            flg2[j] = 0; mvdK[j] = 0.; warmlev[j] = 0;
             if (k >= nzu) continue;
             const int f = flg[j];
-            const double t1 = gt[k], qv1 = gqv[k], pres = gp[k];
-            const double qc1 = (f & F_QC) ? gqc[k] : 0.0;
-            const double qi1 = (f & F_QI) ? gqi[k] : 0.0, ni1 = (f & F_QI) ? gni[k] : 0.0;
-            const double qr1 = (f & F_QR) ? gqr[k] : 0.0, nr1 = (f & F_QR) ? gnr[k] : 0.0;
-            const double qs1 = (f & F_QS) ? gqs[k] : 0.0, qg1 = (f & F_QG) ? gqg[k] : 0.0;
+            // one batch of unconditional loads (one memory round trip), cleaned afterwards as block B did
+            const double t1 = gt[k], qv1 = gqv[k], pres = gp[k], nwfa1 = gnwfa[k], nifa1 = gnifa[k];
+            const double rqc = gqc[k], rqi = gqi[k], rni = gni[k], rqr = gqr[k], rnr = gnr[k], rqs = gqs[k], rqg = gqg[k];
+            const double qc1 = (f & F_QC) ? rqc : 0.0;
+            const double qi1 = (f & F_QI) ? rqi : 0.0, ni1 = (f & F_QI) ? rni : 0.0;
+            const double qr1 = (f & F_QR) ? rqr : 0.0, nr1 = (f & F_QR) ? rnr : 0.0;
+            const double qs1 = (f & F_QS) ? rqs : 0.0, qg1 = (f & F_QG) ? rqg : 0.0;
             double tten = L(V_TTEN, k), qvten = L(V_QVTEN, k), qcten = L(V_QCTEN, k), ncten = L(V_NCTEN, k);
             const double qiten = L(V_QITEN, k), niten = L(V_NITEN, k);
             double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k);
@@ -1117,7 +1119,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             if ((qs1 + qsten * DT) > R1) { rs = (qs1 + qsten * DT) * rho; f2 |= F_QS; }
             if ((qg1 + qgten * DT) > R1) { rg = (qg1 + qgten * DT) * rho; f2 |= F_QG; }
             flg2[j] = f2;
-            warmlev[j] = temp >= 270.65;                     // for k_0 of M:2718-2721
+            warmlev[j] = temp >= 270.65 ? 1 : 0;                     // for k_0 of M:2718-2721
 
             // ---- L: snow moments needed later (smoc/smob only), M:2663-2698 ----
             double xDs = 0.;
@@ -1228,8 +1230,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 
             // qv and the (inert) aerosol numbers are final here: blocks O-Q do not touch them
             gqv[k] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
-            gnwfa[k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (gnwfa[k] + nwfaten * DT)));   // M:3628
-            gnifa[k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (gnifa[k] + 0. * DT)));       // M:3630
+            gnwfa[k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (nwfa1 + nwfaten * DT)));   // M:3628
+            gnifa[k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (nifa1 + 0. * DT)));       // M:3630
 
             L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
             L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
@@ -1242,7 +1244,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         // ============ pass 3: fall speeds, M:3206-3354 ============
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
         double odz[NJ], orho_[NJ], tmp2[NJ];
-        bool ok[NJ];
+        int ok[NJ];
+        double dzv[NJ];
         int nstep_r = 0, nstep_i = 0, nstep_s = 0, nstep_g = 0;
         int ksed_r = 0, ksed_i = 0, ksed_s = 0, ksed_g = 0;
 
@@ -1250,15 +1253,16 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             vtr[j] = vtnr[j] = vti[j] = vtni[j] = vts[j] = vtg[j] = 0.;
-            odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = false;
+            odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = 0; dzv[j] = 1.;
             if (k >= nzu) continue;
             const double rho = L(V_RHO2, k);
-            odz[j] = 1. / gdz[k];
+            dzv[j] = gdz[k];
+            odz[j] = 1. / dzv[j];
             orho_[j] = 1. / rho;
             tmp2[j] = L(V_TEMP2, k);
             const double rr = L(V_RR2, k);
             if (rr > R1) {                                   // M:3221-3233
-                ok[j] = true;
+                ok[j] = 1;
                 const double rhof = sqrt(rho_not / rho);
                 const double nr = L(V_NR2, k);
                 const double lamr = root3(am_r * kc::crg[2] * kc::org2 * nr / rr);
@@ -1276,7 +1280,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 const double vm = fmax(vtr[j], vtnr[j]);
                 if (vm > 1.E-3) {                            // M:3239-3243
                     ks = int(k);
-                    const double delta_tp = gdz[k] / vm;
+                    const double delta_tp = dzv[j] / vm;
                     const int n1 = int(DT / delta_tp + 1.);
                     ns = n1 > ns ? n1 : ns;
                 }
@@ -1316,11 +1320,11 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                ok[j] = false;
+                ok[j] = 0;
                 if (k >= nzu) continue;
                 const double ri = L(V_RI2, k);
                 if (ri > R1) {
-                    ok[j] = true;
+                    ok[j] = 1;
                     const double rhof = sqrt(rho_not / L(V_RHO2, k));
                     const double lami = root3(am_i * kc::cig[1] * kc::oig1 * L(V_NI2, k) / ri);
                     const double ilami = 1. / lami;
@@ -1337,7 +1341,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                     if (k < nzu && vti[j] > 1.E-3) {
                         ks = int(k);
-                        const int n1 = int(DT / (gdz[k] / vti[j]) + 1.);
+                        const int n1 = int(DT / (dzv[j] / vti[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
                 }
@@ -1352,10 +1356,10 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                ok[j] = false; dummy[j] = 0.;
+                ok[j] = 0; dummy[j] = 0.;
                 if (k >= nzu) continue;
                 if (L(V_RS2, k) > R1) {
-                    ok[j] = true;
+                    ok[j] = 1;
                     const double rhof = sqrt(rho_not / L(V_RHO2, k));
                     const double xDs = L(V_XDS, k);
                     const double Mrat = 1. / xDs;
@@ -1384,7 +1388,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                     if (k < nzu && vts[j] > 1.E-3) {
                         ks = int(k);
-                        const int n1 = int(DT / (gdz[k] / vts[j]) + 1.);
+                        const int n1 = int(DT / (dzv[j] / vts[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
                 }
@@ -1398,11 +1402,11 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                ok[j] = false; dummy[j] = 0.;
+                ok[j] = 0; dummy[j] = 0.;
                 if (k >= nzu) continue;
                 const double rg = L(V_RG2, k);
                 if (rg > R1) {
-                    ok[j] = true;
+                    ok[j] = 1;
                     const double rhof = sqrt(rho_not / L(V_RHO2, k));
                     const double N0_exp = n0x2[j];
                     const double lam_exp = root4(N0_exp * am_g * kc::cgg[0] / rg);
@@ -1420,7 +1424,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                     if (k < nzu && vtg[j] > 1.E-3) {
                         ks = int(k);
-                        const int n1 = int(DT / (gdz[k] / vtg[j]) + 1.);
+                        const int n1 = int(DT / (dzv[j] / vtg[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
                 }
@@ -1573,11 +1577,12 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             if (k >= nzu) continue;
             const int f = flg[j];
-            const double qc1 = (f & F_QC) ? gqc[k] : 0.0, nc1 = (f & F_QC) ? gnc[k] : 0.0;
-            const double qi1 = (f & F_QI) ? gqi[k] : 0.0, ni1 = (f & F_QI) ? gni[k] : 0.0;
-            const double qr1 = (f & F_QR) ? gqr[k] : 0.0, nr1 = (f & F_QR) ? gnr[k] : 0.0;
-            const double qs1 = (f & F_QS) ? gqs[k] : 0.0, qg1 = (f & F_QG) ? gqg[k] : 0.0;
-            const double t1 = gt[k];
+            const double rqc = gqc[k], rnc = gnc[k], rqi = gqi[k], rni = gni[k], rqr = gqr[k], rnr = gnr[k],
+                         rqs = gqs[k], rqg = gqg[k], t1 = gt[k];       // one batch, cleaned below (block B)
+            const double qc1 = (f & F_QC) ? rqc : 0.0, nc1 = (f & F_QC) ? rnc : 0.0;
+            const double qi1 = (f & F_QI) ? rqi : 0.0, ni1 = (f & F_QI) ? rni : 0.0;
+            const double qr1 = (f & F_QR) ? rqr : 0.0, nr1 = (f & F_QR) ? rnr : 0.0;
+            const double qs1 = (f & F_QS) ? rqs : 0.0, qg1 = (f & F_QG) ? rqg : 0.0;
             double tten = L(V_TTEN, k), qcten = L(V_QCTEN, k), ncten = L(V_NCTEN, k);
             double qiten = L(V_QITEN, k), niten = L(V_NITEN, k);
             const double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k), qsten = L(V_QSTEN, k), qgten = L(V_QGTEN, k);
