@@ -1,0 +1,98 @@
+"""BASELINE-size runs (-m gpu): size-independent properties of the step, plus oracle spot checks on
+columns sampled from the full batch."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from parity import OUT, TOL, conditioned_mask, max_rel
+
+pytestmark = pytest.mark.gpu
+R1 = 1e-12
+
+
+def _dev(st):
+    return {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+
+
+def _step(m, dev, dt=10.0, nstep=False):
+    ncol = dev["qv"].shape[0]
+    ppt = torch.zeros(ncol, 4, dtype=torch.float64, device="cuda")
+    ns = torch.zeros(ncol, 4, dtype=torch.int32, device="cuda") if nstep else None
+    m.batch_step(dev, dt, ppt, nstep=ns)
+    torch.cuda.synchronize()
+    return ppt, ns
+
+
+def _check_invariants(dev, ppt):
+    for k in OUT:
+        assert bool(torch.isfinite(dev[k]).all()), k
+    assert bool((dev["qv"] >= 1e-10).all())                              # M:3625
+    for q, n in (("qc", "nc"), ("qi", "ni"), ("qr", "nr"), ("qs", None), ("qg", None)):
+        x = dev[q]
+        assert bool(((x == 0.0) | (x > R1)).all()), q                    # species at or below R1 are zeroed (M:3633...)
+        if n:
+            assert bool((dev[n][x == 0.0] == 0.0).all()), n              # ... together with their number
+            assert bool((dev[n][x > 0.0] > 0.0).all()), n
+    assert bool((ppt >= 0.0).all()) and bool(torch.isfinite(ppt).all())
+
+
+def _spot_check(oracle, st0, dev, ppt, idx):
+    s = {k: np.ascontiguousarray(v[idx].copy()) for k, v in st0.items()}
+    ref = {k: v.copy() for k, v in s.items()}
+    rppt = oracle.batch_step(ref, 10.0)
+    mask = conditioned_mask(oracle, s, 10.0, ref)
+    got = {k: dev[k][idx].cpu().numpy() for k in OUT}
+    mx, per = max_rel(got, ref, OUT, mask)
+    assert mx < TOL, per
+    g = ppt[idx].cpu().numpy()
+    assert float(np.max(np.abs(g - rppt) / np.maximum(np.abs(rppt), 1e-12))) < TOL
+    return mask
+
+
+def test_config2_full_size_replicas(gpu_warm, oracle_warm):
+    st0 = cases.config2(10000)
+    dev = _dev(st0)
+    for _ in range(3):
+        ppt, _ = _step(gpu_warm, dev)
+    _check_invariants(dev, ppt)
+    for k in OUT:                                                        # 10^4 replicas stay bit-identical
+        assert bool((dev[k] == dev[k][0:1]).all()), k
+    ref = {k: np.ascontiguousarray(v[:1].copy()) for k, v in st0.items()}
+    for _ in range(3):
+        rppt = oracle_warm.batch_step(ref, 10.0)
+    mx, per = max_rel({k: dev[k][:1].cpu().numpy() for k in OUT}, ref, OUT)
+    assert mx < TOL, per
+
+
+@pytest.mark.parametrize("name", ["config3", "config5"])
+def test_full_size_invariants_split_and_spot_checks(gpu_mixed, oracle_mixed, name):
+    ncol = 100000
+    st0 = getattr(cases, name)(ncol)
+    dev = _dev(st0)
+    ppt, ns = _step(gpu_mixed, dev, nstep=True)
+    _check_invariants(dev, ppt)
+
+    # determinism and batch-split invariance: columns are independent, so two half batches == one batch, bitwise
+    dev2 = _dev(st0)
+    lo = {k: v[: ncol // 2].contiguous() for k, v in dev2.items()}
+    hi = {k: v[ncol // 2:].contiguous() for k, v in dev2.items()}
+    p_lo, _ = _step(gpu_mixed, lo)
+    p_hi, _ = _step(gpu_mixed, hi)
+    for k in OUT:
+        assert torch.equal(torch.cat([lo[k], hi[k]]), dev[k]), k
+    assert torch.equal(torch.cat([p_lo, p_hi]), ppt)
+
+    # oracle spot check on columns drawn from the whole batch
+    rng = np.random.default_rng(7)
+    idx = np.sort(rng.choice(ncol, 96, replace=False))
+    _spot_check(oracle_mixed, st0, dev, ppt, idx)
+
+    nsn = ns.cpu().numpy()
+    if name == "config5":                                                # the sedimentation-heavy case: >= 20 CFL substeps
+        assert np.median(nsn[:, 0]) >= 20 and nsn[:, 0].max() < 60
+        s = {k: np.ascontiguousarray(v[idx[:8]].copy()) for k, v in st0.items()}
+        for c in range(8):
+            col = {k: s[k][c].copy() for k in s}
+            _, _, ns_ref, _ = oracle_mixed.column_step(col, 10.0)
+            assert nsn[idx[c]].tolist() == ns_ref
