@@ -33,6 +33,7 @@ extern "C" {
 #define KIDMP_EHIP         -3   /* a HIP runtime call failed                      */
 #define KIDMP_ENOMEM       -4
 #define KIDMP_ESTATE       -5   /* context not initialised / already finalised    */
+#define KIDMP_EIO          -6   /* cache file missing, unreadable or malformed    */
 
 #define KIDMP_MAX_NZ      256   /* levels per column supported by the kernels     */
 #define KIDMP_NRATES       36   /* process-rate diagnostics, order of M:2967-3119 */
@@ -108,6 +109,18 @@ int kidmp_reduce_ppt_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt,
  * Returns the number of doubles (<0 on error); out may be NULL to query. */
 int64_t kidmp_get_table(kidmp_ctx *ctx, const char *name, double *out, int64_t cap);
 int64_t kidmp_get_const(kidmp_ctx *ctx, const char *name, double *out, int64_t cap);
+
+/* Interop with the reference's table cache (the only checkpoint-like facility of the path, M:3717-3829 and
+ * M:3864-4078): list-directed text files run_data/racg_thompson09.data (6 tables) and
+ * run_data/racs_thompson09.data (12 tables).  kidmp_save_table_cache writes the GPU-built tables so that a
+ * stock KiD run with l_reuse_thompson_lookup=.true. can read them; kidmp_load_table_cache replaces this
+ * context's rain-graupel / rain-snow tables by the files' contents (e.g. written by the reference).
+ * `dir` is the directory holding the two files (the reference hard-codes "run_data"). */
+int kidmp_save_table_cache(kidmp_ctx *ctx, const char *dir);
+int kidmp_load_table_cache(kidmp_ctx *ctx, const char *dir);
+/* The same format on host buffers (no GPU needed): ntab arrays of n_each doubles, Fortran element order. */
+int kidmp_cache_write_file(const char *path, int32_t ntab, const double *const *tabs, int64_t n_each);
+int kidmp_cache_read_file(const char *path, int32_t ntab, double *const *tabs, int64_t n_each);
 
 /* Seconds spent in table construction during kidmp_init (host wall clock). */
 double kidmp_init_seconds(const kidmp_ctx *ctx);

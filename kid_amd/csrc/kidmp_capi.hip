@@ -16,6 +16,7 @@
 #include "thompson_column.h"
 #include "thompson_host_init.h"
 #include "thompson_tables.h"
+#include "table_cache.h"
 
 using namespace kidmp;
 
@@ -156,6 +157,16 @@ int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const v
     for (int i = 0; i < nptr; ++i)
         if (!ptrs[i]) return fail(ctx, KIDMP_EINVAL, "kidmp: null array argument");
     return KIDMP_OK;
+}
+
+struct CacheFamily { const char *file; std::vector<double *> dev; int64_t n; };
+std::vector<CacheFamily> cache_families(Tables &t)
+{
+    return {
+        {"racg_thompson09.data", {t.tcg_racg, t.tmr_racg, t.tcr_gacr, t.tmg_gacr, t.tnr_racg, t.tnr_gacr}, N_RACG},   // M:3823-3828
+        {"racs_thompson09.data", {t.tcs_racs1, t.tmr_racs1, t.tcs_racs2, t.tmr_racs2, t.tcr_sacr1, t.tms_sacr1,
+                                  t.tcr_sacr2, t.tms_sacr2, t.tnr_racs1, t.tnr_racs2, t.tnr_sacr1, t.tnr_sacr2}, N_RACS},   // M:4066-4077
+    };
 }
 
 }  // namespace
@@ -341,6 +352,56 @@ int64_t kidmp_get_const(kidmp_ctx *ctx, const char *name, double *out, int64_t c
             return e.n;
         }
     return fail(ctx, KIDMP_EINVAL, std::string("kidmp_get_const: unknown constant ") + name);
+}
+
+int kidmp_cache_write_file(const char *path, int32_t ntab, const double *const *tabs, int64_t n_each)
+{
+    if (!path || !tabs || ntab <= 0 || n_each <= 0) return fail(nullptr, KIDMP_EINVAL, "kidmp_cache_write_file: bad argument");
+    return cache_write(path, ntab, tabs, n_each) == 0 ? KIDMP_OK : fail(nullptr, KIDMP_EIO, std::string("cannot write ") + path);
+}
+
+int kidmp_cache_read_file(const char *path, int32_t ntab, double *const *tabs, int64_t n_each)
+{
+    if (!path || !tabs || ntab <= 0 || n_each <= 0) return fail(nullptr, KIDMP_EINVAL, "kidmp_cache_read_file: bad argument");
+    const int rc = cache_read(path, ntab, tabs, n_each);
+    if (rc == -1) return fail(nullptr, KIDMP_EIO, std::string("cannot open ") + path);
+    if (rc != 0) return fail(nullptr, KIDMP_EIO, std::string("malformed or short table cache ") + path);
+    return KIDMP_OK;
+}
+
+int kidmp_save_table_cache(kidmp_ctx *ctx, const char *dir)
+{
+    if (!ctx || !ctx->ready || !dir) return fail(ctx, KIDMP_ESTATE, "kidmp_save_table_cache: bad context");
+    if (ctx->hc.iiwarm) return fail(ctx, KIDMP_ESTATE, "kidmp_save_table_cache: iiwarm context has no mixed-phase tables");
+    for (CacheFamily &fam : cache_families(ctx->tables)) {
+        std::vector<std::vector<double>> host(fam.dev.size(), std::vector<double>(size_t(fam.n)));
+        std::vector<const double *> ptr;
+        for (size_t i = 0; i < fam.dev.size(); ++i) {
+            HIPTRY(ctx, hipMemcpy(host[i].data(), fam.dev[i], size_t(fam.n) * sizeof(double), hipMemcpyDeviceToHost));
+            ptr.push_back(host[i].data());
+        }
+        const std::string path = std::string(dir) + "/" + fam.file;
+        if (cache_write(path.c_str(), int(ptr.size()), ptr.data(), fam.n) != 0) return fail(ctx, KIDMP_EIO, "cannot write " + path);
+    }
+    return KIDMP_OK;
+}
+
+int kidmp_load_table_cache(kidmp_ctx *ctx, const char *dir)
+{
+    if (!ctx || !ctx->ready || !dir) return fail(ctx, KIDMP_ESTATE, "kidmp_load_table_cache: bad context");
+    if (ctx->hc.iiwarm) return fail(ctx, KIDMP_ESTATE, "kidmp_load_table_cache: iiwarm context has no mixed-phase tables");
+    for (CacheFamily &fam : cache_families(ctx->tables)) {
+        std::vector<std::vector<double>> host(fam.dev.size(), std::vector<double>(size_t(fam.n)));
+        std::vector<double *> ptr;
+        for (auto &h : host) ptr.push_back(h.data());
+        const std::string path = std::string(dir) + "/" + fam.file;
+        const int rc = cache_read(path.c_str(), int(ptr.size()), ptr.data(), fam.n);
+        if (rc != 0) return fail(ctx, KIDMP_EIO, (rc == -1 ? "cannot open " : "malformed or short table cache ") + path);
+        for (size_t i = 0; i < fam.dev.size(); ++i)
+            HIPTRY(ctx, hipMemcpy(fam.dev[i], host[i].data(), size_t(fam.n) * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIPTRY(ctx, repack_records(ctx->tables, ctx->stream));       // the solver reads the interleaved records
+    return KIDMP_OK;
 }
 
 }  // extern "C"

@@ -422,6 +422,22 @@ __global__ void k_iaus(const Bins *__restrict__ b, const Consts *__restrict__ cp
     t.tpi_ide[id] = ide;
 }
 
+// rebuild the interleaved per-cell records from the planar tables (after kidmp_load_table_cache)
+__global__ void k_repack(Tables t)
+{
+    const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (id < N_RACS) {
+        double *r = t.racs_rec + id * RACS_REC;
+        r[0] = t.tmr_racs1[id]; r[1] = t.tcr_sacr1[id]; r[2] = t.tmr_racs2[id]; r[3] = t.tcr_sacr2[id];
+        r[4] = t.tcs_racs1[id]; r[5] = t.tms_sacr1[id]; r[6] = t.tnr_racs1[id]; r[7] = t.tnr_racs2[id];
+        r[8] = t.tnr_sacr1[id]; r[9] = t.tnr_sacr2[id];
+    }
+    if (id < N_RACG) {
+        double *r = t.racg_rec + id * RACG_REC;
+        r[0] = t.tmr_racg[id]; r[1] = t.tcr_gacr[id]; r[2] = t.tnr_racg[id]; r[3] = t.tnr_gacr[id]; r[4] = t.tcg_racg[id];
+    }
+}
+
 }  // namespace
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return e_; } while (0)
@@ -459,6 +475,14 @@ void free_tables(Tables &t)
         if (all[i]) (void)hipFree(all[i]);
         all[i] = nullptr;
     }
+}
+
+hipError_t repack_records(Tables &t, hipStream_t s)
+{
+    const int T = 256;
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)((N_RACG + T - 1) / T)), dim3(T), 0, s, t);
+    HIPCHK(hipGetLastError());
+    return hipStreamSynchronize(s);
 }
 
 hipError_t build_tables(const Consts *d_consts, const Bins *d_bins, int iiwarm, Tables &t, hipStream_t s)

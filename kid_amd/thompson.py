@@ -79,6 +79,14 @@ def load_library():
     L.kidmp_get_table.argtypes = [_vp, C.c_char_p, _dp, C.c_int64]
     L.kidmp_get_const.restype = C.c_int64
     L.kidmp_get_const.argtypes = [_vp, C.c_char_p, _dp, C.c_int64]
+    L.kidmp_save_table_cache.restype = C.c_int
+    L.kidmp_save_table_cache.argtypes = [_vp, C.c_char_p]
+    L.kidmp_load_table_cache.restype = C.c_int
+    L.kidmp_load_table_cache.argtypes = [_vp, C.c_char_p]
+    L.kidmp_cache_write_file.restype = C.c_int
+    L.kidmp_cache_write_file.argtypes = [C.c_char_p, C.c_int32, C.POINTER(_dp), C.c_int64]
+    L.kidmp_cache_read_file.restype = C.c_int
+    L.kidmp_cache_read_file.argtypes = [C.c_char_p, C.c_int32, C.POINTER(_dp), C.c_int64]
     L.kidmp_init_seconds.restype = C.c_double
     L.kidmp_init_seconds.argtypes = [_vp]
     L.kidmp_kernel_name.restype = C.c_char_p
@@ -214,6 +222,13 @@ class ThompsonMP:
         self._check(L.kidmp_get_const(self._h, name.encode(), _np_ptr(out), n))
         return out
 
+    # ---- the reference's run_data/*.data table caches (M:3717-3829, M:3864-4078) ----
+    def save_table_cache(self, directory):
+        self._check(load_library().kidmp_save_table_cache(self._h, os.fsencode(directory)))
+
+    def load_table_cache(self, directory):
+        self._check(load_library().kidmp_load_table_cache(self._h, os.fsencode(directory)))
+
     @staticmethod
     def kernel_name():
         return load_library().kidmp_kernel_name().decode()
@@ -237,3 +252,26 @@ def mp_thompson(*args, **kw):
     if _module_ctx is None:
         raise KidmpError("mp_thompson called before thompson_init")
     return _module_ctx.mp_thompson(*args, **kw)
+
+
+def cache_write_file(path, tables):
+    """Write `tables` (list of equally sized float64 arrays, Fortran element order) in the list-directed
+    text format of the reference's `write(12,*) table` statements (M:3823-3828)."""
+    arrs = [np.ascontiguousarray(np.asarray(t, dtype=np.float64).ravel(order="F")) for t in tables]
+    n = arrs[0].size
+    if any(a.size != n for a in arrs):
+        raise KidmpError("cache_write_file: tables must have equal sizes")
+    ptrs = (_dp * len(arrs))(*[_np_ptr(a) for a in arrs])
+    rc = load_library().kidmp_cache_write_file(os.fsencode(path), len(arrs), ptrs, n)
+    if rc != 0:
+        raise KidmpError("cache_write_file failed (%d): %s" % (rc, load_library().kidmp_last_error(None).decode()))
+
+
+def cache_read_file(path, ntab, n_each):
+    """Read ntab tables of n_each values written by a Fortran `write(u,*)` (or by cache_write_file)."""
+    arrs = [np.empty(n_each) for _ in range(ntab)]
+    ptrs = (_dp * ntab)(*[_np_ptr(a) for a in arrs])
+    rc = load_library().kidmp_cache_read_file(os.fsencode(path), ntab, ptrs, n_each)
+    if rc != 0:
+        raise KidmpError("cache_read_file failed (%d): %s" % (rc, load_library().kidmp_last_error(None).decode()))
+    return arrs

@@ -166,3 +166,25 @@ def test_multi_step_drift_mixed(gpu_mixed, oracle_mixed):
     # and the survey's known answer for the reference itself (SURVEY 9h KAT-A mixed, 6 digits)
     assert abs(got["qs"].sum() / 4.26247e-2 - 1) < 2e-6
     assert abs(float(ppt[0, 0]) / 1.708898e-2 - 1) < 2e-6
+
+
+def test_table_cache_roundtrip_through_reference_format(gpu_mixed, tmp_path):
+    """kidmp_save_table_cache -> run_data-style text files -> kidmp_load_table_cache into a second context."""
+    from kid_amd import ThompsonMP, cache_read_file
+    d = str(tmp_path)
+    gpu_mixed.save_table_cache(d)
+    racg = cache_read_file(d + "/racg_thompson09.data", 6, 28 * 28 * 37 * 37)
+    assert np.array_equal(racg[1], gpu_mixed.table("tmr_racg"))          # file order of M:3823-3828
+    other = ThompsonMP(iiwarm=False)
+    try:
+        other.load_table_cache(d)
+        for n in ("tcg_racg", "tnr_gacr", "tcs_racs1", "tms_sacr2", "racs_rec", "racg_rec"):
+            assert np.array_equal(other.table(n), gpu_mixed.table(n)), n
+        st = cases.config3(ncol=64)
+        a, pa, _ = _gpu_batch(gpu_mixed, st, 10.0)
+        b, pb, _ = _gpu_batch(other, st, 10.0)
+        for k in OUT:
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(pa, pb)
+    finally:
+        other.close()
