@@ -178,6 +178,45 @@ __device__ inline double root3(double x) { return cbrt(x); }                    
 __device__ inline double root4(double x) { return sqrt(sqrt(x)); }                 // **oge1 = 1/(bm_g+1)
 __device__ inline double root6(double x) { return sqrt(cbrt(x)); }                 // **(1./6.), M:1701
 
+// ---- general powers: x**y = 2**(y*e + y*log2(m)),  x = 2**e * m,  m in [sqrt(1/2), sqrt(2)) ----
+// libm's pow spends most of its ~250 fp64 instructions on an extended-precision logarithm because the
+// error of log2(x) is multiplied by y and by |log2 x| (up to ~40 here).  Splitting off the binary exponent
+// removes that amplification: y*e is formed exactly (product + fma residual), |log2 m| <= 1/2, and only the
+// small remainder r goes through exp2.  For |y| <= 4.2 (every exponent of the scheme) the result is within
+// ~3 ulp of pow (<= 2 ulp for |y| < 1) at ~100 instructions.  x must be positive and finite.
+struct Log2Parts { double e, lg; };                      // log2(x) = e + lg, e integral, |lg| <= 0.5
+__device__ inline Log2Parts log2_parts(double x)
+{
+    int e;
+    double m = frexp(x, &e);                             // m in [0.5, 1)
+    if (m < 0.70710678118654757) { m *= 2.; e -= 1; }    // m in [sqrt(1/2), sqrt(2))
+    Log2Parts p;
+    p.e = double(e);
+    p.lg = log2(m);
+    return p;
+}
+// 2**(t_hi + t_lo + y*log2(x)): t_hi + t_lo is an extra exponent known as an exact sum (0 for a bare power)
+__device__ inline double exp2_parts(const Log2Parts &l, double y, double t_hi, double t_lo)
+{
+    const double p_hi = y * l.e;
+    const double p_lo = fma(y, l.e, -p_hi);              // y*e = p_hi + p_lo exactly
+    const double s = p_hi + t_hi;                        // two-sum: s + s_lo = p_hi + t_hi exactly
+    const double bb = s - p_hi;
+    const double s_lo = (p_hi - (s - bb)) + (t_hi - bb);
+    const double n = rint(s);
+    const double r = (s - n) + (((s_lo + p_lo) + t_lo) + y * l.lg);
+    return ldexp(exp2(r), int(n));
+}
+__device__ inline double fpow(double x, double y) { return exp2_parts(log2_parts(x), y, 0., 0.); }
+// 10**la * x**y in one exponential (the a_*smo2**b_ pattern of the Field et al. moments, M:1572-1574)
+__device__ inline double pow10_times_pow(double la, const Log2Parts &l, double y)
+{
+    const double L10_hi = 3.3219280948873622, L10_lo = 1.6616175169735920e-16;   // log2(10)
+    const double t_hi = la * L10_hi;
+    const double t_lo = fma(la, L10_hi, -t_hi) + la * L10_lo;
+    return exp2_parts(l, y, t_hi, t_lo);
+}
+
 // ---------------- scalar helpers ----------------
 // Decade index of M:1763-1771 and its seven siblings:
 //     nic = NINT(ALOG10(x));  n = first of {nic-1, nic, nic+1} with x/10.**n in [1,10);
@@ -253,11 +292,10 @@ __device__ inline double fit(const double *s, double tc, double x)
     return s[0] + s[1] * tc + s[2] * x + s[3] * tc * x + s[4] * tc * tc + s[5] * x * x
          + s[6] * tc * tc * x + s[7] * tc * x * x + s[8] * tc * tc * tc + s[9] * x * x * x;
 }
-__device__ inline double snow_moment(const Consts &c, double tc0, double order, double smo2)
+__device__ inline double snow_moment(const Log2Parts &lsmo2, double tc0, double order)
 {
-    const double a_ = exp10(fit(kc::sa, tc0, order));
-    const double b_ = fit(kc::sb, tc0, order);
-    return a_ * pow(smo2, b_);
+    // a_ = 10.**loga_ ; moment = a_ * smo2**b_   (M:1595-1600)
+    return pow10_times_pow(fit(kc::sa, tc0, order), lsmo2, fit(kc::sb, tc0, order));
 }
 
 // graupel intercept before the running minimum, M:1639-1647
@@ -507,22 +545,22 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             if (!iiwarm && L_qs) {
                 const double tc0 = fmin(-0.1, temp - 273.15);
                 smob = rs * kc::oams;
-                const double smo2 = smob;                    // bm_s == 2 (M:1553-1554)
+                const Log2Parts lsmo2 = log2_parts(smob);    // smo2 = smob since bm_s == 2 (M:1553-1554)
                 {   // 0th moment, M:1571-1574
                     const double la = kc::sa[0] + kc::sa[1] * tc0 + kc::sa[4] * tc0 * tc0 + kc::sa[8] * tc0 * tc0 * tc0;
                     const double b_ = kc::sb[0] + kc::sb[1] * tc0 + kc::sb[4] * tc0 * tc0 + kc::sb[8] * tc0 * tc0 * tc0;
-                    smo0 = exp10(la) * pow(smo2, b_);
+                    smo0 = pow10_times_pow(la, lsmo2, b_);
                 }
                 {   // 1st moment, M:1577-1587
                     const double la = kc::sa[0] + kc::sa[1] * tc0 + kc::sa[2] + kc::sa[3] * tc0 + kc::sa[4] * tc0 * tc0 + kc::sa[5]
                                     + kc::sa[6] * tc0 * tc0 + kc::sa[7] * tc0 + kc::sa[8] * tc0 * tc0 * tc0 + kc::sa[9];
                     const double b_ = kc::sb[0] + kc::sb[1] * tc0 + kc::sb[2] + kc::sb[3] * tc0 + kc::sb[4] * tc0 * tc0 + kc::sb[5]
                                     + kc::sb[6] * tc0 * tc0 + kc::sb[7] * tc0 + kc::sb[8] * tc0 * tc0 * tc0 + kc::sb[9];
-                    smo1 = exp10(la) * pow(smo2, b_);
+                    smo1 = pow10_times_pow(la, lsmo2, b_);
                 }
-                smoc = snow_moment(c, tc0, kc::cse[0], smo2);  // M:1590-1600
-                smoe = snow_moment(c, tc0, kc::cse[12], smo2); // M:1603-1613
-                smof = snow_moment(c, tc0, kc::cse[15], smo2); // M:1616-1626
+                smoc = snow_moment(lsmo2, tc0, kc::cse[0]);  // M:1590-1600
+                smoe = snow_moment(lsmo2, tc0, kc::cse[12]); // M:1603-1613
+                smof = snow_moment(lsmo2, tc0, kc::cse[15]); // M:1616-1626
             }
 
             // ---- E (per level part): graupel slope/intercept, M:1650-1653 ----
@@ -535,7 +573,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 N0_g = N0_exp / (kc::cgg[1] * lam_exp) * lamg;          // lamg**cge(2), cge(2) = 1
                 if (L_qg) {
                     // ilamg**bv_g is the one general power; cge(9) = 3 + bv_g, cge(10) = 2, cge(11) = 2.5 + bv_g/2
-                    ig_bv = pow(ilamg, bv_g);
+                    ig_bv = fpow(ilamg, bv_g);
                     ig11 = ilamg * ilamg * sqrt(ilamg * ig_bv);
                 }
             }
@@ -1126,7 +1164,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             if (!iiwarm && (f2 & F_QS)) {
                 const double tc0 = fmin(-0.1, temp - 273.15);
                 const double smob = rs * kc::oams;
-                const double smoc = snow_moment(c, tc0, kc::cse[0], smob);
+                const double smoc = snow_moment(log2_parts(smob), tc0, kc::cse[0]);
                 xDs = smoc / smob;                           // smod (M:2701-2711) feeds nothing
             }
 
@@ -1365,13 +1403,13 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     const double Mrat = 1. / xDs;
                     double ils1 = 1. / (Mrat * Lam0 + fv_s);
                     double ils2 = 1. / (Mrat * Lam1 + fv_s);
-                    const double mm = pow(Mrat, mu_s);
-                    const double t1_vts = Kap0 * kc::csg[3] * pow(ils1, kc::cse[3]);
-                    const double t2_vts = Kap1 * mm * kc::csg[9] * pow(ils2, kc::cse[9]);
+                    const double mm = fpow(Mrat, mu_s);
+                    const double t1_vts = Kap0 * kc::csg[3] * fpow(ils1, kc::cse[3]);
+                    const double t2_vts = Kap1 * mm * kc::csg[9] * fpow(ils2, kc::cse[9]);
                     ils1 = 1. / (Mrat * Lam0);
                     ils2 = 1. / (Mrat * Lam1);
                     const double t3_vts = Kap0 * kc::csg[0] * cube(ils1);          // **cse(1), cse(1) = bm_s+1 = 3
-                    const double t4_vts = Kap1 * mm * kc::csg[6] * pow(ils2, kc::cse[6]);
+                    const double t4_vts = Kap1 * mm * kc::csg[6] * fpow(ils2, kc::cse[6]);
                     const double v = rhof * av_s * (t1_vts + t2_vts) / (t3_vts + t4_vts);
                     const double boost = L(V_BOOST, k);
                     if (tmp2[j] > (T_0 + 0.1))
@@ -1412,7 +1450,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     const double lam_exp = root4(N0_exp * am_g * kc::cgg[0] / rg);
                     const double lamg = lam_exp * kc::lamg_fac;
                     const double ilamg = 1. / lamg;
-                    const double v = rhof * av_g * kc::cgg[5] * kc::ogg3 * pow(ilamg, bv_g);
+                    const double v = rhof * av_g * kc::cgg[5] * kc::ogg3 * fpow(ilamg, bv_g);
                     vtg[j] = tmp2[j] > T_0 ? fmax(v, vtr[j]) : v;
                 }
             }
