@@ -469,7 +469,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             L(V_RS, k) = (f & F_QS) ? qs1 : 0.;  L(V_RG, k) = (f & F_QG) ? qg1 : 0.;
             L(V_NI, k) = ni;      L(V_NR, k) = nr;    L(V_QVSI, k) = qvsi;
             L(V_SSATW, k) = ssatw; L(V_SSATI, k) = ssati;
-            L(V_DIFFU, k) = diffusivity(temp, pres);                 // M:1522
+            if (!iiwarm) L(V_DIFFU, k) = diffusivity(temp, pres);    // M:1522 (only the frozen-species block reads it)
         }
 
         // ---- no_micro early return, M:1540.  Block B has already zeroed the
@@ -528,14 +528,13 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             const double rs = L_qs ? L(V_RS, k) * rho : R1, rg = L_qg ? L(V_RG, k) * rho : R1;
             const double ni = L(V_NI, k), nr = L(V_NR, k);
             const double qvsi = L(V_QVSI, k), ssatw = L(V_SSATW, k), ssati = L(V_SSATI, k);
-            const double diffu = L(V_DIFFU, k);
+            const double diffu = iiwarm ? 0. : L(V_DIFFU, k);
             const double nc = L_qc ? Nt_c : 2.;
 
             // cheap thermodynamics of block C recomputed here, M:1504-1532
             const double tempc = temp - 273.15;
             const double rhof = sqrt(rho_not / rho);
             const double rhof2 = sqrt(rhof);
-            const double delQvs = fmax(0.0, rslf(pres, 273.15) - qv);
             const double visco = visc_air(tempc);
             const double vsc2 = sqrt(rho / visco);
             const double tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
@@ -897,6 +896,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                         prs_scw = (1. - g_frac) * prs_scw;
                     }
                 } else {                                     // ---- melting, M:2237-2281 ----
+                    const double delQvs = fmax(0.0, rslf(pres, 273.15) - qv);   // M:1508, only read here
                     if (L_qs) {
                         prr_sml = (tempc * tcond - lvap0 * diffu * delQvs) * (kc::t1_qs_me * smo1 + kc::t2_qs_me * rhof2 * vsc2 * smof);
                         prr_sml = prr_sml + 4218. * olfus * tempc * (prr_rcs + prs_scw);
