@@ -1,0 +1,110 @@
+"""Parity across the kernel's compile-time variants and run-time switches (-m gpu): other nz (NJ = 1..4 level
+groups, every LDS stride), other dt (incl. the dt > 120 s re-routing of M:2277), l_sediment off, other set_Nc,
+degenerate batch sizes, and the C ABI's argument checks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import kat_cases as kc
+from parity import FLOORS, OUT, TOL, conditioned_mask, max_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _resample(col, nz):
+    """KAT-A style column on nz levels spanning the same 15 km (linear interpolation in level index)."""
+    x0 = np.linspace(0.0, 1.0, col["qv"].shape[0])
+    x1 = np.linspace(0.0, 1.0, nz)
+    out = {k: np.interp(x1, x0, v) for k, v in col.items()}
+    out["dz"] = np.full(nz, 15000.0 / nz)
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def _batch(cols):
+    return {k: np.ascontiguousarray(np.stack([c[k] for c in cols])) for k in cases.KEYS}
+
+
+def _compare(m, o, st, dt, tol=TOL, max_excluded_frac=0.08, depletion_aware=False):
+    ref = {k: v.copy() for k, v in st.items()}
+    rppt = o.batch_step(ref, dt)
+    mask = conditioned_mask(o, st, dt, ref)
+    got = {k: v.copy() for k, v in st.items()}
+    gppt, _ = m.batch_step_host(got, dt)
+    if depletion_aware:
+        # With long steps a species can be depleted to 1e-7 of its input in one call (q + qten*dt); the
+        # remainder then carries the input's rounding error, amplified by that ratio.  Measure such values
+        # against 1e-5 of the input instead of against themselves (i.e. allow 1e-15 of the input value).
+        # The number of a depleted species is rebuilt from that remainder (M:3655-3664), so it inherits it.
+        per = {}
+        depleted = {n: np.abs(ref[q]) < 1e-5 * np.abs(st[q]) for q, n in (("qc", "nc"), ("qi", "ni"), ("qr", "nr"))}
+        for k in OUT:
+            scale = np.maximum(np.maximum(np.abs(ref[k]), FLOORS[k]), 1e-5 * np.abs(st[k]))
+            ok = mask & ~depleted[k] if k in depleted else mask
+            per[k] = float(np.max(np.where(ok, np.abs(got[k] - ref[k]) / scale, 0.0)))
+        mx = max(per.values())
+    else:
+        mx, per = max_rel(got, ref, OUT, mask)
+    pm = float(np.max(np.abs(gppt - rppt) / np.maximum(np.abs(rppt), 1e-12)))
+    assert mx < tol and pm < tol, (per, pm)
+    assert (~mask).sum() <= max_excluded_frac * mask.size
+
+
+@pytest.mark.parametrize("nz", [2, 17, 40, 64, 65, 100, 119, 121, 128, 129, 150, 192, 200, 256])
+def test_other_level_counts(gpu_mixed, oracle_mixed, nz):
+    cols = [_resample(kc.kat_a(True), nz), _resample(kc.kat_a(False), nz), _resample(kc.kat_c(), nz)]
+    _compare(gpu_mixed, oracle_mixed, _batch(cols), 10.0)
+
+
+@pytest.mark.parametrize("dt", [1.0, 5.0, 30.0, 60.0, 150.0])
+def test_other_time_steps(gpu_mixed, oracle_mixed, dt):
+    st = cases.edge_cases()
+    _compare(gpu_mixed, oracle_mixed, st, dt, max_excluded_frac=0.2, depletion_aware=dt > 10.0)
+
+
+def test_switches_l_sediment_off_and_other_set_nc():
+    from kid_amd import ThompsonMP
+    from oracle.oracle import Oracle
+    for kw in (dict(iiwarm=False, set_Nc=100.0, l_sediment=False), dict(iiwarm=False, set_Nc=300.0, l_sediment=True),
+               dict(iiwarm=True, set_Nc=50.0, l_sediment=True)):
+        m, o = ThompsonMP(**kw), Oracle(**kw)
+        try:
+            st = cases.edge_cases()
+            rho = 0.622 * st["p"] / (287.04 * st["t"] * (st["qv"] + 0.622))
+            st["nc"] = kw["set_Nc"] * 1e6 / rho
+            if kw["iiwarm"]:
+                for k in ("qi", "ni", "qs", "qg"):
+                    st[k][:] = 0.0
+            _compare(m, o, st, 10.0, max_excluded_frac=0.2)
+        finally:
+            m.close()
+            o.close()
+
+
+def test_degenerate_batches(gpu_mixed, oracle_mixed):
+    one = {k: v[:1].copy() for k, v in cases.edge_cases().items()}
+    _compare(gpu_mixed, oracle_mixed, one, 10.0)
+    empty = {k: np.zeros((0, 120)) for k in cases.KEYS}
+    ppt, _ = gpu_mixed.batch_step_host(empty, 10.0)
+    assert ppt.shape == (0, 4)
+
+
+def test_c_abi_argument_checks(gpu_mixed):
+    from kid_amd import KidmpError
+    from kid_amd.thompson import load_library
+    L = load_library()
+    st = {k: v[:1].copy() for k, v in cases.edge_cases().items()}
+    with pytest.raises(KidmpError):
+        gpu_mixed.batch_step_host({k: v[:, :1].copy() for k, v in st.items()}, 10.0)       # nz = 1
+    with pytest.raises(KidmpError):
+        gpu_mixed.batch_step_host({k: np.zeros((1, 300)) for k in cases.KEYS}, 10.0)       # nz > KIDMP_MAX_NZ
+    with pytest.raises(KidmpError):
+        gpu_mixed.batch_step_host(st, 0.0)                                                 # dt <= 0
+    dp = C.POINTER(C.c_double)
+    args = [st[k].ctypes.data_as(dp) for k in cases.KEYS]
+    args[3] = None                                                                          # null qr pointer
+    ppt = np.zeros(4)
+    rc = L.kidmp_batch_step_host(gpu_mixed._h, 1, 120, 10.0, *args, ppt.ctypes.data_as(dp), None)
+    assert rc == -1 and b"null" in L.kidmp_last_error(gpu_mixed._h)
+    assert L.kidmp_batch_step_host(None, 1, 120, 10.0, *args, ppt.ctypes.data_as(dp), None) == -5
