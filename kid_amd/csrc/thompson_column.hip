@@ -462,7 +462,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             warmlev[j] = temp >= 270.65 ? 1 : 0;
             flg[j] = f;
 
-            L(V_TEMP, k) = temp;  L(V_QV, k) = qv;    L(V_RHO, k) = rho;
+            L(V_TEMP, k) = temp;  L(V_QV, k) = i_qv[j];   L(V_RHO, k) = rho;     // qv raw: block K needs qv1d itself
             // the cleaned mixing ratios (block B zeroes q <= R1, M:1412...) go to LDS; pass 1 rebuilds
             // rc..rg = q*rho from them with the same product, and block J reads them directly
             L(V_RC, k) = (f & F_QC) ? qc1 : 0.;  L(V_RI, k) = (f & F_QI) ? qi1 : 0.;  L(V_RR, k) = (f & F_QR) ? qr1 : 0.;
@@ -514,18 +514,25 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         }
 
         if (a.debug_stop == 1) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
-        // ============ pass 1: blocks D-J, M:1545-2569 ============
+        // ============ pass 1: blocks D-J (M:1545-2569), then K, L(snow), rain PSD, M, N (M:2574-2960) ============
+        // Blocks K-N are pointwise in k and only consume the tendencies of block J, so they run in the same
+        // sweep over the level: the tendencies stay in registers and no input is read twice.
+        double mvdK[NJ];
+        int flg2[NJ];
 #pragma unroll 1
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+            flg2[j] = 0; mvdK[j] = 0.; warmlev[j] = 0;
             if (k >= nzu) continue;
             const int f = flg[j];
             const bool L_qc = f & F_QC, L_qi = f & F_QI, L_qr = f & F_QR, L_qs = f & F_QS, L_qg = f & F_QG;
-            const double pres = gp[k];
-            const double temp = L(V_TEMP, k), qv = L(V_QV, k), rho = L(V_RHO, k);
+            const double pres = gp[k], nwfa1 = gnwfa[k], nifa1 = gnifa[k];
+            const double temp = L(V_TEMP, k), qv_raw = L(V_QV, k), rho = L(V_RHO, k);
+            const double qv = fmax(1.E-10, qv_raw);
             const double rc = L_qc ? L(V_RC, k) * rho : R1, ri = L_qi ? L(V_RI, k) * rho : R1,
                          rr = L_qr ? L(V_RR, k) * rho : R1;
-            const double rs = L_qs ? L(V_RS, k) * rho : R1, rg = L_qg ? L(V_RG, k) * rho : R1;
+            const double qs1c = L(V_RS, k), qg1c = L(V_RG, k);
+            const double rs = L_qs ? qs1c * rho : R1, rg = L_qg ? qg1c * rho : R1;
             const double ni = L(V_NI, k), nr = L(V_NR, k);
             const double qvsi = L(V_QVSI, k), ssatw = L(V_SSATW, k), ssati = L(V_SSATI, k);
             const double diffu = iiwarm ? 0. : L(V_DIFFU, k);
@@ -1071,10 +1078,6 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 tten = (lfus * ocp * (-prr_sml - prr_gml - prr_rcg - prr_rcs) + lsub * ocp * (prs_sde + prg_gde)) * orho;
             }
 
-            L(V_TTEN, k) = tten;   L(V_QVTEN, k) = qvten; L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
-            L(V_QITEN, k) = qiten; L(V_NITEN, k) = niten; L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
-            L(V_QSTEN, k) = qsten; L(V_QGTEN, k) = qgten; L(V_PRRGML, k) = prr_gml; L(V_BOOST, k) = vts_boost;
-
             if (RATES) {                                     // save_dg order of M:2967-3119 (two of them in pass 2)
                 gdouble *g = grates + k;
                 if (!iiwarm) {
@@ -1092,29 +1095,19 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 g[int64_t(33) * nz] = pnr_wau;
                 g[int64_t(35) * nz] = pnr_rcr;
             }
-        }
 
-        if (a.debug_stop == 2) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
-        // ============ pass 2: blocks K, L(snow), rain PSD, M, N; M:2574-2960 ============
-        double mvdK[NJ];
-        int flg2[NJ];
-#pragma unroll 1
-        for (int j = 0; j < NJ; ++j) {
-            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-            flg2[j] = 0; mvdK[j] = 0.; warmlev[j] = 0;
-            if (k >= nzu) continue;
-            const int f = flg[j];
-            // one batch of unconditional loads (one memory round trip), cleaned afterwards as block B did
-            const double t1 = gt[k], qv1 = gqv[k], pres = gp[k], nwfa1 = gnwfa[k], nifa1 = gnifa[k];
-            const double rqc = gqc[k], rqi = gqi[k], rni = gni[k], rqr = gqr[k], rnr = gnr[k], rqs = gqs[k], rqg = gqg[k];
-            const double qc1 = (f & F_QC) ? rqc : 0.0;
-            const double qi1 = (f & F_QI) ? rqi : 0.0, ni1 = (f & F_QI) ? rni : 0.0;
-            const double qr1 = (f & F_QR) ? rqr : 0.0, nr1 = (f & F_QR) ? rnr : 0.0;
-            const double qs1 = (f & F_QS) ? rqs : 0.0, qg1 = (f & F_QG) ? rqg : 0.0;
-            double tten = L(V_TTEN, k), qvten = L(V_QVTEN, k), qcten = L(V_QCTEN, k), ncten = L(V_NCTEN, k);
-            const double qiten = L(V_QITEN, k), niten = L(V_NITEN, k);
-            double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k);
-            const double qsten = L(V_QSTEN, k), qgten = L(V_QGTEN, k), prr_gml = L(V_PRRGML, k);
+            // ---------------- blocks K-N for the same level ----------------
+            const double tten_J = tten, qvten_J = qvten, qcten_J = qcten, ncten_J = ncten, qiten_J = qiten,
+                         niten_J = niten, qrten_J = qrten, nrten_J = nrten, qsten_J = qsten, qgten_J = qgten,
+                         prr_gml_J = prr_gml, boost_J = vts_boost, t1_J = temp, qc1_J = qc1, qi1_J = qi1, ni1_J = ni1,
+                         qr1_J = qr1, nr1_J = nr1;
+            {
+            const double t1 = t1_J, qv1 = qv_raw;
+            const double qc1 = qc1_J, qi1 = qi1_J, ni1 = ni1_J, qr1 = qr1_J, nr1 = nr1_J, qs1 = qs1c, qg1 = qg1c;
+            double tten = tten_J, qvten = qvten_J, qcten = qcten_J, ncten = ncten_J;
+            const double qiten = qiten_J, niten = niten_J;
+            double qrten = qrten_J, nrten = nrten_J;
+            const double qsten = qsten_J, qgten = qgten_J, prr_gml = prr_gml_J;
             double nwfaten = 0.;
 
             // ---- K, M:2575-2655 ----
@@ -1273,9 +1266,12 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 
             L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
             L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
+            L(V_QITEN, k) = qiten; L(V_NITEN, k) = niten; L(V_QSTEN, k) = qsten; L(V_QGTEN, k) = qgten;
+            L(V_BOOST, k) = boost_J;
             L(V_TEMP2, k) = temp;  L(V_RHO2, k) = rho;    L(V_RI2, k) = ri;  L(V_NI2, k) = ni;
             L(V_RR2, k) = rr;      L(V_NR2, k) = nr;      L(V_RS2, k) = rs;  L(V_RG2, k) = rg;
             L(V_XDS, k) = xDs;     L(V_OCP, k) = ocp;     L(V_LVAP, k) = lvap;
+            }   // blocks K-N
         }
 
         if (a.debug_stop == 3) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
