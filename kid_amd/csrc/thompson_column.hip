@@ -160,6 +160,23 @@ __device__ inline void shift_from_above(const double (&s)[NJ], double (&up)[NJ])
 }
 
 
+// Per-group values (arr[j], j < NJ) that are touched inside a non-unrolled loop over j: a run-time subscript
+// would force the array onto the scratch stack, so the element is chosen by compare/select instead.
+template <class T, int NJ>
+__device__ inline T pick(const T (&arr)[NJ], int j)
+{
+    T v = arr[0];
+#pragma unroll
+    for (int i = 1; i < NJ; ++i) v = (j == i) ? arr[i] : v;
+    return v;
+}
+template <class T, int NJ>
+__device__ inline void put(T (&arr)[NJ], int j, T v)
+{
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) arr[i] = (j == i) ? v : arr[i];
+}
+
 // ---- powers with exponents fixed by the scheme's PARAMETERs ----
 // The reference writes x**cre(n) etc. with run-time exponents, but every one of
 // them is a compile-time constant of the scheme (M:452-553 from bm_*, bv_*, mu_*).
@@ -383,9 +400,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         gdouble *grates = RATES ? uniform_ptr(a.rates + col * int64_t(KIDMP_NRATES_) * nz) : nullptr;
 
         // ============ pass 0: blocks B + C, M:1387-1533 ============
-        int flg[NJ];
+        int pst[NJ];              // per level group: bits 0-4 L_q* of block B, bits 8-12 L_q* of block K, bit 16 T >= 270.65
         double mvdB[NJ], rgB[NJ];
-        int warmlev[NJ];
         bool any_micro = false;
         // all first-touch HBM loads of the column are issued together (one round trip):
         double i_t[NJ], i_qv[NJ], i_p[NJ], i_qc[NJ], i_qi[NJ], i_qr[NJ], i_qs[NJ], i_qg[NJ], i_ni[NJ], i_nr[NJ];
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-            flg[j] = 0; mvdB[j] = 0.; rgB[j] = R1; warmlev[j] = 0;
+            pst[j] = 0; mvdB[j] = 0.; rgB[j] = R1;
             if (k >= nzu) continue;
             const double temp = i_t[j];
             const double qv = fmax(1.E-10, i_qv[j]);
@@ -459,8 +475,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             if (fabs(ssatw) < eps) ssatw = 0.0;
             if (fabs(ssati) < eps) ssati = 0.0;
             if (f != 0 || ssati > 0.0) any_micro = true;
-            warmlev[j] = temp >= 270.65 ? 1 : 0;
-            flg[j] = f;
+            pst[j] = f | (temp >= 270.65 ? 1 << 16 : 0);
 
             L(V_TEMP, k) = temp;  L(V_QV, k) = i_qv[j];   L(V_RHO, k) = rho;     // qv raw: block K needs qv1d itself
             // the cleaned mixing ratios (block B zeroes q <= R1, M:1412...) go to LDS; pass 1 rebuilds
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             int k0l = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                if (warmlev[j]) k0l = lane + WAVE * j;
+                if (pst[j] >> 16) k0l = lane + WAVE * j;
             const int k_0 = wave_max_i(k0l);
             double n0[NJ];
 #pragma unroll
@@ -503,7 +518,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                 n0[j] = __builtin_inf();
                 if (k < nzu)
-                    n0[j] = graupel_N0(int(k) > k_0 && (flg[j] & F_QR) && mvdB[j] > 100.E-6, mvdB[j], rgB[j]);
+                    n0[j] = graupel_N0(int(k) > k_0 && (pst[j] & F_QR) && mvdB[j] > 100.E-6, mvdB[j], rgB[j]);
             }
             suffix_min<NJ>(n0);
 #pragma unroll
@@ -518,13 +533,13 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         // Blocks K-N are pointwise in k and only consume the tendencies of block J, so they run in the same
         // sweep over the level: the tendencies stay in registers and no input is read twice.
         double mvdK[NJ];
-        int flg2[NJ];
 #pragma unroll 1
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-            flg2[j] = 0; mvdK[j] = 0.; warmlev[j] = 0;
+            put(mvdK, j, 0.);
+            put(pst, j, pick(pst, j) & 31);
             if (k >= nzu) continue;
-            const int f = flg[j];
+            const int f = pick(pst, j) & 31;
             const bool L_qc = f & F_QC, L_qi = f & F_QI, L_qr = f & F_QR, L_qs = f & F_QS, L_qg = f & F_QG;
             const double pres = gp[k], nwfa1 = gnwfa[k], nifa1 = gnifa[k];
             const double temp = L(V_TEMP, k), qv_raw = L(V_QV, k), rho = L(V_RHO, k);
@@ -1145,12 +1160,11 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 double mvd = (3.0 + mu_r + 0.672) / lr;
                 if (mvd > 2.5E-3)           { mvd = 2.5E-3;      nr = nr_from_mvd(c, rr, mvd); }
                 else if (mvd < D0r * 0.75)  { mvd = D0r * 0.75;  nr = nr_from_mvd(c, rr, mvd); }
-                mvdK[j] = mvd;
+                put(mvdK, j, mvd);
             }
             if ((qs1 + qsten * DT) > R1) { rs = (qs1 + qsten * DT) * rho; f2 |= F_QS; }
             if ((qg1 + qgten * DT) > R1) { rg = (qg1 + qgten * DT) * rho; f2 |= F_QG; }
-            flg2[j] = f2;
-            warmlev[j] = temp >= 270.65 ? 1 : 0;                     // for k_0 of M:2718-2721
+            put(pst, j, f | (f2 << 8) | (temp >= 270.65 ? 1 << 16 : 0));     // temp: for k_0 of M:2718-2721
 
             // ---- L: snow moments needed later (smoc/smob only), M:2663-2698 ----
             double xDs = 0.;
@@ -1335,7 +1349,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 int k0l = 0;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    if (warmlev[j]) k0l = lane + WAVE * j;
+                    if (pst[j] >> 16) k0l = lane + WAVE * j;
                 const int k_0 = wave_max_i(k0l);
                 double n0[NJ];
 #pragma unroll
@@ -1343,7 +1357,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                     n0[j] = __builtin_inf();
                     if (k < nzu)
-                        n0[j] = graupel_N0(int(k) > k_0 && (flg2[j] & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L(V_RG2, k));
+                        n0[j] = graupel_N0(int(k) > k_0 && ((pst[j] >> 8) & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L(V_RG2, k));
                 }
                 suffix_min<NJ>(n0);
 #pragma unroll
@@ -1610,7 +1624,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             if (k >= nzu) continue;
-            const int f = flg[j];
+            const int f = pick(pst, j) & 31;
             const double rqc = gqc[k], rnc = gnc[k], rqi = gqi[k], rni = gni[k], rqr = gqr[k], rnr = gnr[k],
                          rqs = gqs[k], rqg = gqg[k], t1 = gt[k];       // one batch, cleaned below (block B)
             const double qc1 = (f & F_QC) ? rqc : 0.0, nc1 = (f & F_QC) ? rnc : 0.0;
