@@ -1293,7 +1293,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
         double odz[NJ], orho_[NJ], tmp2[NJ];
         int ok[NJ];
-        double dzv[NJ];
+        double dzv[NJ], rhofv[NJ];   // rhof(k) = SQRT(RHO_NOT/rho(k)), refreshed once per level (M:3219)
         int nstep_r = 0, nstep_i = 0, nstep_s = 0, nstep_g = 0;
         int ksed_r = 0, ksed_i = 0, ksed_s = 0, ksed_g = 0;
 
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             vtr[j] = vtnr[j] = vti[j] = vtni[j] = vts[j] = vtg[j] = 0.;
-            odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = 0; dzv[j] = 1.;
+            odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = 0; dzv[j] = 1.; rhofv[j] = 0.;
             if (k >= nzu) continue;
             const double rho = L(V_RHO2, k);
             dzv[j] = gdz[k];
@@ -1309,9 +1309,10 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             orho_[j] = 1. / rho;
             tmp2[j] = L(V_TEMP2, k);
             const double rr = L(V_RR2, k);
+            const double rhof = sqrt(rho_not / rho);
+            rhofv[j] = rhof;
             if (rr > R1) {                                   // M:3221-3233
                 ok[j] = 1;
-                const double rhof = sqrt(rho_not / rho);
                 const double nr = L(V_NR2, k);
                 const double lamr = root3(am_r * kc::crg[2] * kc::org2 * nr / rr);
                 vtr[j] = rhof * av_r * kc::crg[5] * kc::org3 * pw4(lamr) * (1. / pw5(lamr + fv_r));          // cre(3)=4, cre(6)=5
@@ -1373,7 +1374,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 const double ri = L(V_RI2, k);
                 if (ri > R1) {
                     ok[j] = 1;
-                    const double rhof = sqrt(rho_not / L(V_RHO2, k));
+                    const double rhof = rhofv[j];
                     const double lami = root3(am_i * kc::cig[1] * kc::oig1 * L(V_NI2, k) / ri);
                     const double ilami = 1. / lami;
                     const double pw = ilami;                             // ilami**bv_i, bv_i = 1
@@ -1408,7 +1409,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 if (k >= nzu) continue;
                 if (L(V_RS2, k) > R1) {
                     ok[j] = 1;
-                    const double rhof = sqrt(rho_not / L(V_RHO2, k));
+                    const double rhof = rhofv[j];
                     const double xDs = L(V_XDS, k);
                     const double Mrat = 1. / xDs;
                     double ils1 = 1. / (Mrat * Lam0 + fv_s);
@@ -1455,7 +1456,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
                 const double rg = L(V_RG2, k);
                 if (rg > R1) {
                     ok[j] = 1;
-                    const double rhof = sqrt(rho_not / L(V_RHO2, k));
+                    const double rhof = rhofv[j];
                     const double N0_exp = n0x2[j];
                     const double lam_exp = root4(N0_exp * am_g * kc::cgg[0] / rg);
                     const double lamg = lam_exp * kc::lamg_fac;
