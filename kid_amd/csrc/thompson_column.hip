@@ -41,6 +41,10 @@ namespace kidmp {
 namespace {
 
 constexpr int WAVE = 64;
+#ifndef KIDMP_WPB
+#define KIDMP_WPB 1
+#endif
+constexpr int WPB = KIDMP_WPB;          // waves (= columns) per workgroup; 2 measured equal to 1 on MI355X
 
 // ---------------- wave primitives ----------------
 // Cross-lane work stays on the VALU: DPP row shifts inside the four 16-lane rows, v_readlane to
@@ -371,10 +375,11 @@ __device__ inline gdouble *uniform_ptr(const double *p)
 // NJ = level groups per lane (ceil(nz/64)); NL = LDS stride per slot (>= nz), a compile-time
 // constant so that every slot address is "one VGPR (8k) + immediate offset (slot*NL*8)".
 template <int NJ, int NL, bool RATES>
-__global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a)
+__global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepArgs a)
 {
-    __shared__ double Lsh[NSLOT * NL];               // [NSLOT][NL]
-#define L(slot, k) Lsh[(slot) * NL + (k)]
+    __shared__ double Lsh[WPB][NSLOT * NL];          // one private [NSLOT][NL] image per wave (= per column)
+    double *const Lw = Lsh[threadIdx.x / WAVE];
+#define L(slot, k) Lw[(slot) * NL + (k)]
 
     const Consts &c = g_consts[a.cslot];
     const Tables &tb = a.tables;
@@ -388,7 +393,8 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
     const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
     const double Nt_c = c.Nt_c;
 
-    for (int64_t col = blockIdx.x; col < a.ncol; col += gridDim.x) {
+    // WPB independent waves per workgroup, one column each: fewer, larger workgroups to dispatch
+    for (int64_t col = int64_t(blockIdx.x) * WPB + threadIdx.x / WAVE; col < a.ncol; col += int64_t(gridDim.x) * WPB) {
         if (a.debug_stop == 9) continue;                     // profiling aid: launch floor
         const int64_t base = col * int64_t(nz);
         // the 12 state profiles are read and written in place (no __restrict__); bases are wave-uniform
@@ -1712,7 +1718,7 @@ __global__ __launch_bounds__(WAVE, 2) void thompson_column_step(const StepArgs a
             const double qg = qg1 + qgten * DT;
             gqg[k] = qg <= R1 ? 0.0 : qg;
         }
-        __syncthreads();     // LDS is reused by the next column of this block
+        // (a wave's LDS image is private and its DS operations are ordered: no barrier between columns)
     }
 }
 
@@ -1751,8 +1757,9 @@ hipError_t upload_consts(int slot, const Consts &c)
 template <int NJ, int NL>
 static hipError_t launch_nj(const StepArgs &a, bool rates, int grid, hipStream_t s)
 {
-    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, true>), dim3(grid), dim3(WAVE), 0, s, a);
-    else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, false>), dim3(grid), dim3(WAVE), 0, s, a);
+    const int g = (grid + WPB - 1) / WPB;
+    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, true>), dim3(g), dim3(WPB * WAVE), 0, s, a);
+    else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, false>), dim3(g), dim3(WPB * WAVE), 0, s, a);
     return hipGetLastError();
 }
 

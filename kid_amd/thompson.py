@@ -41,7 +41,8 @@ class _Cfg(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libkidmp.so")
+    # KIDMP_LIB: tuning aid only (A/B builds of the same library); the default is the in-tree build
+    return os.environ.get("KIDMP_LIB") or os.path.join(_HERE, "libkidmp.so")
 
 
 _lib = None
