@@ -48,14 +48,15 @@ def make_workload(name, ncol):
 
 def measured_traffic(workload, ncol):
     """HBM bytes per launch of the column-step kernel from a committed rocprofv3 --pmc run of this
-    same workload (profiles/pmc_<workload>.json, made by tools/pmc_profile.sh; FETCH_SIZE and
+    same workload (profiles/rNN_pmc_<workload>.json, made by tools/pmc_profile.sh; FETCH_SIZE and
     WRITE_SIZE are in KiB and come from separate passes).  On gfx950 FETCH_SIZE reports half of the
     bytes of a coalesced stream; tools/calibrate_fetch.sh measured 1/1.84 for this kernel's 8-byte-
     per-lane loads on a known byte count, so the read side is doubled (MI355X_MICROARCH.md, HBM)."""
-    path = os.path.join(ROOT, "profiles", "pmc_%s.json" % workload)
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % workload)))
+    if not found:
         return None
-    d = json.load(open(path))
+    d = json.load(open(found[-1]))                  # the latest round's profile
     if int(d.get("ncol", ncol)) != ncol or "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
         return None
     return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0

@@ -1,4 +1,4 @@
-﻿!mod$ v1 sum:029fbc6991bede03
+﻿!mod$ v1 sum:5a47d1a420dbd21d
 !need$ 732c0bf8568496f5 n parameters
 !need$ 95f9d21f04c7c2f9 n column_variables
 !need$ 63943bc4c828cc73 n physconst
@@ -50,6 +50,25 @@ integer(4)::ih
 integer(4)::imom
 character(200_4,1)::name
 character(200_4,1)::units
+integer(4),parameter,private::s_qv=1_4
+integer(4),parameter,private::s_qc=2_4
+integer(4),parameter,private::s_qi=3_4
+integer(4),parameter,private::s_qr=4_4
+integer(4),parameter,private::s_qs=5_4
+integer(4),parameter,private::s_qg=6_4
+integer(4),parameter,private::s_ni=7_4
+integer(4),parameter,private::s_nr=8_4
+integer(4),parameter,private::s_nc=9_4
+integer(4),parameter,private::s_nwfa=10_4
+integer(4),parameter,private::s_nifa=11_4
+integer(4),parameter,private::s_t=12_4
+integer(4),parameter,private::nslot=12_4
+integer(4),parameter,private::nhyd=7_4
+integer(4),parameter,private::hyd_slot(1_8:7_8)=[INTEGER(4)::2_4,4_4,8_4,3_4,7_4,5_4,6_4]
+integer(4),parameter,private::hyd_spec(1_8:7_8)=[INTEGER(4)::1_4,2_4,2_4,3_4,3_4,4_4,5_4]
+integer(4),parameter,private::hyd_mom(1_8:7_8)=[INTEGER(4)::1_4,1_4,2_4,1_4,2_4,1_4,1_4]
+integer(4),parameter,private::dg_spec(1_8:4_8)=[INTEGER(4)::2_4,3_4,4_4,5_4]
+integer(4),parameter,private::dg_row(1_8:4_8)=[INTEGER(4)::1_4,4_4,2_4,3_4]
 contains
 subroutine mphys_thompson09_interfacen()
 end

@@ -1,15 +1,19 @@
 !
-! mphys_thompson09n -- drop-in replacement for the KiD adapter of the same name
-! (/root/reference/mphys_thompson09n.f90, "W:").  Same module name, same public
-! entry `mphys_thompson09_interfacen` (no arguments; all data through KiD's
-! column_variables / parameters / physconst modules, W:11-17), same outputs:
-! d*_mphys tendencies (W:198-245) and the surface-precipitation diagnostics
-! through save_dg (W:155-192, W:248-303).
+! mphys_thompson09n -- KiD-facing adapter of the MI355X Thompson-09n build.
 !
-! What changes: the `do i=1,nx` loop around mp_thompson (W:54-246) becomes one
-! batched call -- all nx columns go to the MI355X in a single launch -- and the
-! inputs the reference leaves unset (nc1d, nwfa1d, nifa1d, w1d; W:36) get the
-! scheme's own non-aerosol defaults (M:958-964).
+! Drop-in for the reference adapter of the same name (/root/reference/mphys_thompson09n.f90, "W:"): same module
+! name, same public entry `mphys_thompson09_interfacen` without arguments, data exchanged through KiD's own
+! modules (parameters, column_variables, physconst, namelists, diagnostics; W:11-17), same results:
+!   * d*_mphys tendencies = (state after microphysics - state)/dt - forcing          (W:198-245)
+!   * surface precipitation diagnostics through save_dg, in the reference's order     (W:155-182, W:248-303)
+!
+! Design differences (see INTEGRATION.md):
+!   * the reference loops `do i=1,nx` over one-column mp_thompson calls (W:54-246); here the nx columns are
+!     packed once into a (nz, nx, slot) work array -- k fastest, KiD's own order, which is also the layout of the
+!     C ABI -- and advanced by ONE batched call (one GPU launch);
+!   * species are handled by a small slot table instead of one hand-written statement per species;
+!   * the inputs the reference passes unset (nc1d, nwfa1d, nifa1d, w1d; W:36) get the scheme's non-aerosol
+!     defaults (module_mp_thompson09n.f90 of the reference, lines 958-964).
 !
 module mphys_thompson09n
 
@@ -23,144 +27,121 @@ module mphys_thompson09n
 
   Implicit None
 
+  ! public module variables of the reference adapter (W:22-24)
   logical :: micro_unset=.True.
   integer:: ih, imom
   character(max_char_len) :: name, units
+
+  ! slots of the packed state, in the argument order of mp_thompson / the C ABI
+  integer, parameter, private :: S_QV=1, S_QC=2, S_QI=3, S_QR=4, S_QS=5, S_QG=6, S_NI=7, S_NR=8, &
+       S_NC=9, S_NWFA=10, S_NIFA=11, S_T=12, NSLOT=12
+  ! prognostic hydrometeor moments KiD carries for this scheme: (state slot, KiD species, KiD moment)
+  ! KiD species: 1 cloud, 2 rain, 3 ice, 4 snow, 5 graupel; moment 1 mass, 2 number (W:66-93)
+  integer, parameter, private :: NHYD = 7
+  integer, parameter, private :: hyd_slot(NHYD) = (/ S_QC, S_QR, S_NR, S_QI, S_NI, S_QS, S_QG /)
+  integer, parameter, private :: hyd_spec(NHYD) = (/ 1,    2,    2,    3,    3,    4,    5    /)
+  integer, parameter, private :: hyd_mom (NHYD) = (/ 1,    1,    2,    1,    2,    1,    1    /)
+  ! precipitation diagnostics in the reference's call order rain, ice, snow, graupel (W:158-177):
+  ! KiD species index and row of ppt(4,:) = (rain, snow, graupel, ice)
+  integer, parameter, private :: dg_spec(4) = (/ 2, 3, 4, 5 /)
+  integer, parameter, private :: dg_row (4) = (/ 1, 4, 2, 3 /)
 
 contains
 
   Subroutine mphys_thompson09_interfacen
 
-    real :: t2d(nz,nx), p2d(nz,nx), dz2d(nz,nx), w2d(nz,nx), qv2d(nz,nx), qc2d(nz,nx), qr2d(nz,nx), &
-         nr2d(nz,nx), qi2d(nz,nx), ni2d(nz,nx), qs2d(nz,nx), qg2d(nz,nx), nc2d(nz,nx), nwfa2d(nz,nx), &
-         nifa2d(nz,nx)
-    real :: ppt(4,nx), rho
-    real :: pptrain_2d(nx), pptsnow_2d(nx), pptgraul_2d(nx), pptice_2d(nx)
-    integer :: i, k
+    real :: st(nz,nx,NSLOT), pres(nz,nx), wvel(nz,nx), dzc(nz,nx), ppt(4,nx), total(nx), rho
+    integer :: i, k, m, s
 
-    qi2d = 0.0; ni2d = 0.0; qs2d = 0.0; qg2d = 0.0          ! W:46-52
-    w2d = 0.0
-    ppt = 0.0                                                 ! W:55-58
-
-    do i=1,nx                                                 ! gather, W:59-97
-       do k=1,nz
-          t2d(k,i) = (theta(k,i) + (dtheta_adv(k,i)+dtheta_div(k,i))*dt )*exner(k,i)
-          p2d(k,i) = p0*exner(k,i)**(1./r_on_cp)
-          dz2d(k,i) = dz(k)
-          qv2d(k,i) = qv(k,i) + (dqv_adv(k,i)+dqv_div(k,i))*dt
-          qc2d(k,i) = hydrometeors(k,i,1)%moments(1,1) &
-               + (dhydrometeors_adv(k,i,1)%moments(1,1) + dhydrometeors_div(k,i,1)%moments(1,1))*dt
-          qr2d(k,i) = hydrometeors(k,i,2)%moments(1,1) &
-               + (dhydrometeors_adv(k,i,2)%moments(1,1) + dhydrometeors_div(k,i,2)%moments(1,1))*dt
-          nr2d(k,i) = hydrometeors(k,i,2)%moments(1,2) &
-               + (dhydrometeors_adv(k,i,2)%moments(1,2) + dhydrometeors_div(k,i,2)%moments(1,2))*dt
-          if (.not. iiwarm) then
-             qi2d(k,i) = hydrometeors(k,i,3)%moments(1,1) &
-                  + (dhydrometeors_adv(k,i,3)%moments(1,1) + dhydrometeors_div(k,i,3)%moments(1,1))*dt
-             ni2d(k,i) = hydrometeors(k,i,3)%moments(1,2) &
-                  + (dhydrometeors_adv(k,i,3)%moments(1,2) + dhydrometeors_div(k,i,3)%moments(1,2))*dt
-             qs2d(k,i) = hydrometeors(k,i,4)%moments(1,1) &
-                  + (dhydrometeors_adv(k,i,4)%moments(1,1) + dhydrometeors_div(k,i,4)%moments(1,1))*dt
-             qg2d(k,i) = hydrometeors(k,i,5)%moments(1,1) &
-                  + (dhydrometeors_adv(k,i,5)%moments(1,1) + dhydrometeors_div(k,i,5)%moments(1,1))*dt
-          end if
-          ! non-aerosol defaults for what the reference leaves unset (W:36; M:958-964)
-          rho = 0.622*p2d(k,i)/(287.04*t2d(k,i)*(qv2d(k,i)+0.622))
-          nc2d(k,i) = set_Nc*1.e6/rho
-          nwfa2d(k,i) = 11.1E6/rho
-          nifa2d(k,i) = 0.5E6*0.01/rho
+    ! ---- gather: state + (advective + divergence forcing)*dt, W:59-97 ----
+    st = 0.0                                     ! frozen species stay zero in warm runs (W:46-52, W:78)
+    do i = 1, nx
+       st(:,i,S_T)  = (theta(:,i) + (dtheta_adv(:,i) + dtheta_div(:,i))*dt)*exner(:,i)
+       pres(:,i)    = p0*exner(:,i)**(1./r_on_cp)
+       dzc(:,i)     = dz(:)
+       st(:,i,S_QV) = qv(:,i) + (dqv_adv(:,i) + dqv_div(:,i))*dt
+    end do
+    do m = 1, NHYD
+       if (iiwarm .and. hyd_spec(m) > 2) cycle
+       s = hyd_slot(m)
+       do i = 1, nx
+          do k = 1, nz
+             st(k,i,s) = hydrometeors(k,i,hyd_spec(m))%moments(1,hyd_mom(m)) &
+                  + (dhydrometeors_adv(k,i,hyd_spec(m))%moments(1,hyd_mom(m)) &
+                  +  dhydrometeors_div(k,i,hyd_spec(m))%moments(1,hyd_mom(m)))*dt
+          end do
+       end do
+    end do
+    ! what the reference leaves unset: droplet / aerosol numbers from the non-aerosol defaults, no updraft
+    wvel = 0.0
+    do i = 1, nx
+       do k = 1, nz
+          rho = 0.622*pres(k,i)/(287.04*st(k,i,S_T)*(st(k,i,S_QV)+0.622))
+          st(k,i,S_NC)   = set_Nc*1.e6/rho
+          st(k,i,S_NWFA) = 11.1E6/rho
+          st(k,i,S_NIFA) = 0.5E6*0.01/rho
        end do
     end do
 
-    if (micro_unset) then                                     ! W:100-103
+    if (micro_unset) then                        ! W:100-103
        call thompson_init
-       micro_unset=.False.
+       micro_unset = .False.
     end if
 
-    call mp_thompson_batch(nx, nz, dt, qv2d, qc2d, qi2d, qr2d, qs2d, qg2d, ni2d, nr2d, &
-         nc2d, nwfa2d, nifa2d, t2d, p2d, w2d, dz2d, ppt)       ! W:143-152, all columns at once
+    ! ---- all nx columns in one call (replaces the loop around W:143-152) ----
+    ppt = 0.0
+    call mp_thompson_batch(nx, nz, dt, st(:,:,S_QV), st(:,:,S_QC), st(:,:,S_QI), st(:,:,S_QR), st(:,:,S_QS), &
+         st(:,:,S_QG), st(:,:,S_NI), st(:,:,S_NR), st(:,:,S_NC), st(:,:,S_NWFA), st(:,:,S_NIFA), st(:,:,S_T), &
+         pres, wvel, dzc, ppt)
 
-    pptrain_2d = ppt(1,:); pptsnow_2d = ppt(2,:); pptgraul_2d = ppt(3,:); pptice_2d = ppt(4,:)
-
-    if (nx == 1) then                                         ! W:155-182
-       imom=1
-       ih=2
-       name='surface_ppt_for_'//trim(h_names(ih))
-       units=trim(mom_units(imom))//' m'
-       call save_dg(pptrain_2d(1), name, i_dgtime,  units, dim='time')
-       ih=3
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptice_2d(1), name, i_dgtime,  units, dim='time')
-       ih=4
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptsnow_2d(1), name, i_dgtime,  units, dim='time')
-       ih=5
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptgraul_2d(1), name, i_dgtime,  units, dim='time')
-       name='total_surface_ppt'
-       call save_dg((pptice_2d(1)+pptrain_2d(1)+pptsnow_2d(1)+pptgraul_2d(1))/nx, name, i_dgtime, &
-            units, dim='time')
-    end if
-
-    do i=1,nx                                                 ! back out tendencies, W:198-245
-       do k=1,nz
-          dtheta_mphys(k,i)=(t2d(k,i)/exner(k,i)-theta(k,i))/dt - ( dtheta_adv(k,i)+dtheta_div(k,i))
-          dqv_mphys(k,i)=(qv2d(k,i) - qv(k,i))/dt - ( dqv_adv(k,i)+dqv_div(k,i))
-          dhydrometeors_mphys(k,i,1)%moments(1,1)= (qc2d(k,i)-hydrometeors(k,i,1)%moments(1,1))/dt &
-               - (dhydrometeors_adv(k,i,1)%moments(1,1) + dhydrometeors_div(k,i,1)%moments(1,1))
-          dhydrometeors_mphys(k,i,2)%moments(1,1)= (qr2d(k,i)-hydrometeors(k,i,2)%moments(1,1))/dt &
-               - (dhydrometeors_adv(k,i,2)%moments(1,1) + dhydrometeors_div(k,i,2)%moments(1,1))
-          dhydrometeors_mphys(k,i,2)%moments(1,2)= (nr2d(k,i)-hydrometeors(k,i,2)%moments(1,2))/dt &
-               - (dhydrometeors_adv(k,i,2)%moments(1,2) + dhydrometeors_div(k,i,2)%moments(1,2))
-          if (.not.iiwarm)then
-             dhydrometeors_mphys(k,i,3)%moments(1,1)= (qi2d(k,i)-hydrometeors(k,i,3)%moments(1,1))/dt &
-                  - (dhydrometeors_adv(k,i,3)%moments(1,1) + dhydrometeors_div(k,i,3)%moments(1,1))
-             dhydrometeors_mphys(k,i,3)%moments(1,2)= (ni2d(k,i)-hydrometeors(k,i,3)%moments(1,2))/dt &
-                  - (dhydrometeors_adv(k,i,3)%moments(1,2) + dhydrometeors_div(k,i,3)%moments(1,2))
-             dhydrometeors_mphys(k,i,4)%moments(1,1)= (qs2d(k,i)-hydrometeors(k,i,4)%moments(1,1))/dt &
-                  - (dhydrometeors_adv(k,i,4)%moments(1,1) + dhydrometeors_div(k,i,4)%moments(1,1))
-             dhydrometeors_mphys(k,i,5)%moments(1,1)= (qg2d(k,i)-hydrometeors(k,i,5)%moments(1,1))/dt &
-                  - (dhydrometeors_adv(k,i,5)%moments(1,1) + dhydrometeors_div(k,i,5)%moments(1,1))
-          end if
+    ! ---- back out the microphysics tendencies, W:198-245 ----
+    do i = 1, nx
+       dtheta_mphys(:,i) = (st(:,i,S_T)/exner(:,i) - theta(:,i))/dt - (dtheta_adv(:,i) + dtheta_div(:,i))
+       dqv_mphys(:,i)    = (st(:,i,S_QV) - qv(:,i))/dt - (dqv_adv(:,i) + dqv_div(:,i))
+    end do
+    do m = 1, NHYD
+       if (iiwarm .and. hyd_spec(m) > 2) cycle
+       s = hyd_slot(m)
+       do i = 1, nx
+          do k = 1, nz
+             dhydrometeors_mphys(k,i,hyd_spec(m))%moments(1,hyd_mom(m)) = &
+                  (st(k,i,s) - hydrometeors(k,i,hyd_spec(m))%moments(1,hyd_mom(m)))/dt &
+                  - (dhydrometeors_adv(k,i,hyd_spec(m))%moments(1,hyd_mom(m)) &
+                  +  dhydrometeors_div(k,i,hyd_spec(m))%moments(1,hyd_mom(m)))
+          end do
        end do
     end do
 
-    if (nx > 1) then                                          ! W:248-303, same call order
-       imom=1
-       units=trim(mom_units(imom))//' m'
-       ! domain means
-       ih=2
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptrain_2d/nx, name, i_dgtime,  units, dim='time')
-       ih=3
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptice_2d/nx, name, i_dgtime,  units, dim='time')
-       ih=4
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptsnow_2d/nx, name, i_dgtime,  units, dim='time')
-       ih=5
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptgraul_2d/nx, name, i_dgtime,  units, dim='time')
-       name='total_surface_ppt'
-       call save_dg((pptice_2d+pptrain_2d+pptsnow_2d+pptgraul_2d)/nx, name, i_dgtime, units, dim='time')
-       ! all horizontal columns
-       ih=2
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptrain_2d, name, i_dgtime,  units, dim='time')
-       ih=3
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptice_2d, name, i_dgtime,  units, dim='time')
-       ih=4
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptsnow_2d, name, i_dgtime,  units, dim='time')
-       ih=5
-       name='surface_ppt_for_'//trim(h_names(ih))
-       call save_dg(pptgraul_2d, name, i_dgtime,  units, dim='time')
-       name='total_surface_ppt'
-       call save_dg((pptice_2d+pptrain_2d+pptsnow_2d+pptgraul_2d), name, i_dgtime, units, dim='time')
-       ! the reference also saves 'total_ppt_level' from pptrain_2d_prof (W:305-307), an array it
-       ! never assigns (W:191 is commented out): not emitted.
-    endif
+    ! ---- surface precipitation diagnostics ----
+    imom = 1
+    units = trim(mom_units(imom))//' m'
+    total = ppt(4,:) + ppt(1,:) + ppt(2,:) + ppt(3,:)          ! ice + rain + snow + graupel, as W:181
+    if (nx == 1) then                                          ! W:155-182
+       do m = 1, 4
+          ih = dg_spec(m)
+          name = 'surface_ppt_for_'//trim(h_names(ih))
+          call save_dg(ppt(dg_row(m),1), name, i_dgtime, units, dim='time')
+       end do
+       name = 'total_surface_ppt'
+       call save_dg(total(1)/nx, name, i_dgtime, units, dim='time')
+    else                                                       ! W:248-303: domain means, then every column
+       do m = 1, 4
+          ih = dg_spec(m)
+          name = 'surface_ppt_for_'//trim(h_names(ih))
+          call save_dg(ppt(dg_row(m),:)/nx, name, i_dgtime, units, dim='time')
+       end do
+       name = 'total_surface_ppt'
+       call save_dg(total/nx, name, i_dgtime, units, dim='time')
+       do m = 1, 4
+          ih = dg_spec(m)
+          name = 'surface_ppt_for_'//trim(h_names(ih))
+          call save_dg(ppt(dg_row(m),:), name, i_dgtime, units, dim='time')
+       end do
+       name = 'total_surface_ppt'
+       call save_dg(total, name, i_dgtime, units, dim='time')
+       ! 'total_ppt_level' (W:305-307) would save pptrain_2d_prof, an array the reference never assigns
+       ! (W:191 is commented out): not emitted.
+    end if
 
   end Subroutine mphys_thompson09_interfacen
 
