@@ -87,6 +87,19 @@ __device__ inline int wave_max_i(int v)
     return max(max(r0, r1), max(r2, r3));
 }
 
+// highest level lane + 64 j whose predicate holds (0 if none); uniform, from the ballots
+template <int NJ>
+__device__ inline int top_level(const bool (&p)[NJ])
+{
+    int ks = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const unsigned long long m = __ballot(p[j]);
+        if (m) ks = 63 - __clzll((long long)m) + WAVE * j;
+    }
+    return ks;
+}
+
 // x[j] <- min over all levels at or above (lane + 64 j)   (suffix scan from the column top)
 template <int NJ>
 __device__ inline void suffix_min(double (&x)[NJ])
@@ -111,44 +124,35 @@ __device__ inline void suffix_min(double (&x)[NJ])
     }
 }
 
-// a[j], b[j] <- value at the nearest level at or above that has ok, else 0
-// (the "vtXk(k) = vtXk(k+1)" carry of M:3235, 3267, 3307, 3333)
-template <int NJ>
-__device__ inline void carry_down2(double (&a)[NJ], double (&b)[NJ], const int (&okin)[NJ])
+// a[j] (and b[j]) <- value at the nearest level at or above that has ok, else 0
+// (the "vtXk(k) = vtXk(k+1)" carry of M:3235, 3267, 3307, 3333).
+// The nearest valid level is found arithmetically from the ballot of `ok` (first set bit at or above the own
+// lane) and fetched with one bpermute per 32-bit half; groups are chained from the top through lane 0.
+__device__ inline double bperm_d(double v, int src_lane)
 {
-    const int row = lane_id() >> 4;
-    double ca = 0., cb = 0.;
-    int cok = 0;
+    const long long vv = __double_as_longlong(v);
+    const unsigned lo = unsigned(__builtin_amdgcn_ds_bpermute(src_lane << 2, int(unsigned(vv))));
+    const unsigned hi = unsigned(__builtin_amdgcn_ds_bpermute(src_lane << 2, int(unsigned(vv >> 32))));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int NJ, bool TWO>
+__device__ inline void carry_down(double (&a)[NJ], double (&b)[NJ], const int (&okin)[NJ])
+{
+    const int lane = lane_id();
+    double ca = 0., cb = 0.;                             // value carried in from the groups above (0: none)
 #pragma unroll
     for (int j = NJ - 1; j >= 0; --j) {
-        double va = a[j], vb = b[j];
-        int ok = okin[j] ? 1 : 0;
-#define CARRY_STEP(N)                                                     \
-        {                                                                 \
-            const int oo = dpp_i<DPP_ROW_SHL + N>(0, ok);                 \
-            const double oa = dpp_d<DPP_ROW_SHL + N>(0., va);             \
-            const double ob = dpp_d<DPP_ROW_SHL + N>(0., vb);             \
-            if (!ok) { va = oa; vb = ob; ok = oo; }                       \
+        const unsigned long long m = __ballot(okin[j] != 0) >> lane;     // bit i: lane+i is valid
+        const bool found = m != 0ull;
+        const int src = found ? lane + __ffsll((long long)m) - 1 : lane;
+        const double fa = bperm_d(a[j], src);
+        a[j] = found ? fa : ca;
+        if (TWO) {
+            const double fb = bperm_d(b[j], src);
+            b[j] = found ? fb : cb;
         }
-        CARRY_STEP(1) CARRY_STEP(2) CARRY_STEP(4) CARRY_STEP(8)
-#undef CARRY_STEP
-        // row heads (lanes 16, 32, 48) now hold their row's nearest valid value; chain them downward
-        int k3 = __builtin_amdgcn_readlane(ok, 48);  double a3 = readlane_d(va, 48), b3 = readlane_d(vb, 48);
-        if (!k3) { k3 = cok; a3 = ca; b3 = cb; }
-        int k2 = __builtin_amdgcn_readlane(ok, 32);  double a2 = readlane_d(va, 32), b2 = readlane_d(vb, 32);
-        if (!k2) { k2 = k3; a2 = a3; b2 = b3; }
-        int k1 = __builtin_amdgcn_readlane(ok, 16);  double a1 = readlane_d(va, 16), b1 = readlane_d(vb, 16);
-        if (!k1) { k1 = k2; a1 = a2; b1 = b2; }
-        if (!ok) {
-            ok = row == 3 ? cok : (row == 2 ? k3 : (row == 1 ? k2 : k1));
-            va = row == 3 ? ca : (row == 2 ? a3 : (row == 1 ? a2 : a1));
-            vb = row == 3 ? cb : (row == 2 ? b3 : (row == 1 ? b2 : b1));
-        }
-        a[j] = ok ? va : 0.;
-        b[j] = ok ? vb : 0.;
-        cok = __builtin_amdgcn_readlane(ok, 0);
-        ca = readlane_d(va, 0);
-        cb = readlane_d(vb, 0);
+        ca = readlane_d(a[j], 0);
+        if (TWO) cb = readlane_d(b[j], 0);
     }
 }
 
@@ -1325,23 +1329,23 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 vtnr[j] = rhof * av_r * kc::crg[6] / kc::crg[11] * pw2h(lamr) * (1. / pw3h(lamr + fv_r));   // cre(12)=2.5, cre(7)=3.5
             }
         }
-        carry_down2<NJ>(vtr, vtnr, ok);
+        carry_down<NJ, true>(vtr, vtnr, ok);
         {
-            int ns = 0, ks = 0;
+            int ns = 0;
+            bool falls[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                if (k >= nzu) continue;
                 const double vm = fmax(vtr[j], vtnr[j]);
-                if (vm > 1.E-3) {                            // M:3239-3243
-                    ks = int(k);
+                falls[j] = k < nzu && vm > 1.E-3;            // M:3239-3243
+                if (falls[j]) {
                     const double delta_tp = dzv[j] / vm;
                     const int n1 = int(DT / delta_tp + 1.);
                     ns = n1 > ns ? n1 : ns;
                 }
             }
             nstep_r = wave_max_i(ns);
-            ksed_r = wave_max_i(ks);
+            ksed_r = top_level<NJ>(falls);
             if (ksed_r == kte) ksed_r = kte - 1;
         }
         double onstep_r = 1.0, onstep_i = 1.0, onstep_s = 1.0, onstep_g = 1.0;
@@ -1388,20 +1392,21 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                     vtni[j] = rhof * av_i * kc::cig[5] / kc::cig[6] * pw;
                 }
             }
-            carry_down2<NJ>(vti, vtni, ok);
+            carry_down<NJ, true>(vti, vtni, ok);
             {
-                int ns = 0, ks = 0;
+                int ns = 0;
+                bool falls[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                    if (k < nzu && vti[j] > 1.E-3) {
-                        ks = int(k);
+                    falls[j] = k < nzu && vti[j] > 1.E-3;
+                    if (falls[j]) {
                         const int n1 = int(DT / (dzv[j] / vti[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
                 }
                 nstep_i = wave_max_i(ns);
-                ksed_i = wave_max_i(ks);
+                ksed_i = top_level<NJ>(falls);
                 if (ksed_i == kte) ksed_i = kte - 1;
                 if (nstep_i > 0) onstep_i = 1. / double(nstep_i);
             }
@@ -1435,20 +1440,21 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                         vts[j] = v * boost;
                 }
             }
-            carry_down2<NJ>(vts, dummy, ok);
+            carry_down<NJ, false>(vts, dummy, ok);
             {
-                int ns = 0, ks = 0;
+                int ns = 0;
+                bool falls[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                    if (k < nzu && vts[j] > 1.E-3) {
-                        ks = int(k);
+                    falls[j] = k < nzu && vts[j] > 1.E-3;
+                    if (falls[j]) {
                         const int n1 = int(DT / (dzv[j] / vts[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
                 }
                 nstep_s = wave_max_i(ns);
-                ksed_s = wave_max_i(ks);
+                ksed_s = top_level<NJ>(falls);
                 if (ksed_s == kte) ksed_s = kte - 1;
                 if (nstep_s > 0) onstep_s = 1. / double(nstep_s);
             }
@@ -1471,20 +1477,21 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                     vtg[j] = tmp2[j] > T_0 ? fmax(v, vtr[j]) : v;
                 }
             }
-            carry_down2<NJ>(vtg, dummy, ok);
+            carry_down<NJ, false>(vtg, dummy, ok);
             {
-                int ns = 0, ks = 0;
+                int ns = 0;
+                bool falls[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                    if (k < nzu && vtg[j] > 1.E-3) {
-                        ks = int(k);
+                    falls[j] = k < nzu && vtg[j] > 1.E-3;
+                    if (falls[j]) {
                         const int n1 = int(DT / (dzv[j] / vtg[j]) + 1.);
                         ns = n1 > ns ? n1 : ns;
                     }
                 }
                 nstep_g = wave_max_i(ns);
-                ksed_g = wave_max_i(ks);
+                ksed_g = top_level<NJ>(falls);
                 if (ksed_g == kte) ksed_g = kte - 1;
                 if (nstep_g > 0) onstep_g = 1. / double(nstep_g);
             }
