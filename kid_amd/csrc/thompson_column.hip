@@ -376,6 +376,23 @@ __device__ inline gdouble *uniform_ptr(const double *p)
     return (gdouble *)((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
+__device__ inline gdouble *gptr(const double *p, int64_t off)
+{
+    return (gdouble *)reinterpret_cast<unsigned long long>(p) + off;
+}
+
+// The kernel arguments, read where they are used.  The by-value StepArgs parameter sits at offset 0 of the
+// kernarg segment; fetching a field through this (opaque) pointer is one scalar load at the point of use.
+// Loading all 27 pointers at kernel entry instead keeps ~54 SGPRs live for the whole kernel, which the
+// register allocator can only honour by parking them in VGPR lanes (a v_readlane pair per later use).
+typedef const __attribute__((address_space(4))) StepArgs CArgs;
+__device__ inline CArgs *kargs()
+{
+    CArgs *p = (CArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // NJ = level groups per lane (ceil(nz/64)); NL = LDS stride per slot (>= nz), a compile-time
 // constant so that every slot address is "one VGPR (8k) + immediate offset (slot*NL*8)".
 template <int NJ, int NL, bool RATES>
@@ -386,7 +403,6 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
 #define L(slot, k) Lw[(slot) * NL + (k)]
 
     const Consts &c = g_consts[a.cslot];
-    const Tables &tb = a.tables;
     const int lane = lane_id();
     const int nz = a.nz;
     __builtin_assume(nz >= 2 && nz <= 4 * WAVE);          // checked by launch_column_step
@@ -397,30 +413,36 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
     const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
     const double Nt_c = c.Nt_c;
 
-    // WPB independent waves per workgroup, one column each: fewer, larger workgroups to dispatch
-    for (int64_t col = int64_t(blockIdx.x) * WPB + threadIdx.x / WAVE; col < a.ncol; col += int64_t(gridDim.x) * WPB) {
+    // One column per wave, one launch covers all columns (grid = ncol / WPB workgroups).  Deliberately not a
+    // grid-stride loop: a loop invites the compiler to hoist every column-invariant scalar (dt-derived values,
+    // the debug switches, lane predicates) to kernel entry and keep them in SGPRs across the whole body,
+    // and those are the SGPRs it then spills.  `continue` below leaves the column.
+    const int64_t col = int64_t(blockIdx.x) * WPB + threadIdx.x / WAVE;
+    if (col >= a.ncol) return;
+    do {
         if (a.debug_stop == 9) continue;                     // profiling aid: launch floor
         const int64_t base = col * int64_t(nz);
-        // the 12 state profiles are read and written in place (no __restrict__); bases are wave-uniform
-        gdouble *gqv = uniform_ptr(a.qv + base), *gqc = uniform_ptr(a.qc + base), *gqi = uniform_ptr(a.qi + base),
-                *gqr = uniform_ptr(a.qr + base), *gqs = uniform_ptr(a.qs + base), *gqg = uniform_ptr(a.qg + base),
-                *gni = uniform_ptr(a.ni + base), *gnr = uniform_ptr(a.nr + base), *gnc = uniform_ptr(a.nc + base),
-                *gnwfa = uniform_ptr(a.nwfa + base), *gnifa = uniform_ptr(a.nifa + base), *gt = uniform_ptr(a.t + base);
-        const gdouble *gp = uniform_ptr(a.p + base), *gdz = uniform_ptr(a.dz + base);
-        gdouble *grates = RATES ? uniform_ptr(a.rates + col * int64_t(KIDMP_NRATES_) * nz) : nullptr;
-
+        // the 12 state profiles are read and written in place (no __restrict__); bases are wave-uniform and
+        // rebuilt from the kernel arguments at each use (see kargs())
         // ============ pass 0: blocks B + C, M:1387-1533 ============
         int pst[NJ];              // per level group: bits 0-4 L_q* of block B, bits 8-12 L_q* of block K, bit 16 T >= 270.65
         double mvdB[NJ], rgB[NJ];
         bool any_micro = false;
         // all first-touch HBM loads of the column are issued together (one round trip):
         double i_t[NJ], i_qv[NJ], i_p[NJ], i_qc[NJ], i_qi[NJ], i_qr[NJ], i_qs[NJ], i_qg[NJ], i_ni[NJ], i_nr[NJ];
+        {
+        CArgs *ka = kargs();
+        const gdouble *gt = gptr(ka->t, base), *gqv = gptr(ka->qv, base), *gp = gptr(ka->p, base),
+                      *gqc = gptr(ka->qc, base), *gqi = gptr(ka->qi, base), *gqr = gptr(ka->qr, base),
+                      *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base), *gni = gptr(ka->ni, base),
+                      *gnr = gptr(ka->nr, base);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             const unsigned kc = k < nzu ? k : kteu;                 // clamped: loads stay unconditional
             i_t[j] = gt[kc];   i_qv[j] = gqv[kc]; i_p[j] = gp[kc];   i_qc[j] = gqc[kc]; i_qi[j] = gqi[kc];
             i_qr[j] = gqr[kc]; i_qs[j] = gqs[kc]; i_qg[j] = gqg[kc]; i_ni[j] = gni[kc]; i_nr[j] = gnr[kc];
+        }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -500,6 +522,11 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
         // ---- no_micro early return, M:1540.  Block B has already zeroed the
         //      species at or below R1 in the caller's arrays (M:1412-1413 ...).
         if (!__any(any_micro)) {
+            CArgs *ka = kargs();
+            gdouble *gqc = gptr(ka->qc, base), *gnc = gptr(ka->nc, base), *gqi = gptr(ka->qi, base),
+                    *gni = gptr(ka->ni, base), *gqr = gptr(ka->qr, base), *gnr = gptr(ka->nr, base),
+                    *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base);
+            gdouble *grates = RATES ? gptr(ka->rates, col * int64_t(KIDMP_NRATES_) * nz) : nullptr;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
@@ -511,7 +538,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 if (RATES)
                     for (int r = 0; r < KIDMP_NRATES_; ++r) grates[int64_t(r) * nz + k] = 0.;
             }
-            if (a.nstep && lane < 4) a.nstep[col * 4 + lane] = 0;
+            if (ka->nstep && lane < 4) ka->nstep[col * 4 + lane] = 0;
             continue;
         }
 
@@ -538,7 +565,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             }
         }
 
-        if (a.debug_stop == 1) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+        if (a.debug_stop == 1) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 1: blocks D-J (M:1545-2569), then K, L(snow), rain PSD, M, N (M:2574-2960) ============
         // Blocks K-N are pointwise in k and only consume the tendencies of block J, so they run in the same
         // sweep over the level: the tendencies stay in registers and no input is read twice.
@@ -551,7 +578,9 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             if (k >= nzu) continue;
             const int f = pick(pst, j) & 31;
             const bool L_qc = f & F_QC, L_qi = f & F_QI, L_qr = f & F_QR, L_qs = f & F_QS, L_qg = f & F_QG;
-            const double pres = gp[k], nwfa1 = gnwfa[k], nifa1 = gnifa[k];
+            CArgs *ka1 = kargs();
+            const double pres = gptr(ka1->p, base)[k], nwfa1 = gptr(ka1->nwfa, base)[k], nifa1 = gptr(ka1->nifa, base)[k];
+            gdouble *grates = RATES ? gptr(ka1->rates, col * int64_t(KIDMP_NRATES_) * nz) : nullptr;
             const double temp = L(V_TEMP, k), qv_raw = L(V_QV, k), rho = L(V_RHO, k);
             const double qv = fmax(1.E-10, qv_raw);
             const double rc = L_qc ? L(V_RC, k) * rho : R1, ri = L_qi ? L(V_RI, k) * rho : R1,
@@ -671,7 +700,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 idx = idx > 1 ? idx : 1;
                 int jc = int(mvd_c * 1.E6);
                 jc = jc < 1 ? 1 : (jc > nbins ? nbins : jc);
-                const double Ef_rw = tb.t_Efrw[(idx - 1) + nbins * (jc - 1)];
+                const double Ef_rw = kargs()->tables.t_Efrw[(idx - 1) + nbins * (jc - 1)];
                 const double coll = 1. / pw4(lamr + fv_r);               // (lamr+fv_r)**(-cre(9)), cre(9) = 4
                 prr_rcw = rhof * kc::t1_qr_qc * Ef_rw * rc * N0_r * coll;
                 prr_rcw = fmin(rc * odts, prr_rcw);
@@ -734,7 +763,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                         int idx = 1 + int(nbins * log(xDs / kc::Ds1) / log(kc::Dsn / kc::Ds1));
                         idx = idx < nbins ? idx : nbins;
                         idx = idx > 1 ? idx : 1;
-                        const double Ef_sw = tb.t_Efsw[(idx - 1) + nbins * (jc - 1)];
+                        const double Ef_sw = kargs()->tables.t_Efsw[(idx - 1) + nbins * (jc - 1)];
                         prs_scw = rhof * kc::t1_qs_qc * Ef_sw * rc * smoe;
                         pnc_scw = rhof * kc::t1_qs_qc * Ef_sw * nc * smoe;
                         pnc_scw = fmin(nc * odts, pnc_scw);
@@ -762,7 +791,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 if (rr >= kc::r_r1) {
                     if (rs >= kc::r_s1) {
                         const int64_t id = (idx_s - 1) + int64_t(ntb_s) * ((idx_t - 1) + int64_t(ntb_t) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_r - 1)));
-                        const double *r = tb.racs_rec + id * RACS_REC;
+                        const double *r = kargs()->tables.racs_rec + id * RACS_REC;
                         const double tmr_racs1 = r[0], tcr_sacr1 = r[1], tmr_racs2 = r[2], tcr_sacr2 = r[3],
                                      tcs_racs1 = r[4], tms_sacr1 = r[5];
                         if (temp < T_0) {
@@ -784,7 +813,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                     }
                     if (rg >= kc::r_g1) {
                         const int64_t id = (idx_g1 - 1) + int64_t(ntb_g1) * ((idx_g - 1) + int64_t(ntb_g) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_r - 1)));
-                        const double *r = tb.racg_rec + id * RACG_REC;
+                        const double *r = kargs()->tables.racg_rec + id * RACG_REC;
                         if (temp < T_0) {
                             prg_rcg = r[0] + r[1];
                             prg_rcg = fmin(rr * odts, prg_rcg);
@@ -807,7 +836,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
 
                     if (rr > kc::r_r1) {                       // Bigg freezing, M:2066-2086
                         const int64_t id = (idx_r - 1) + int64_t(ntb_r) * ((idx_r1 - 1) + int64_t(ntb_r1) * (idx_tc - 1));
-                        const double *r = tb.qrfz_rec + id * QRFZ_REC;
+                        const double *r = kargs()->tables.qrfz_rec + id * QRFZ_REC;
                         prg_rfz = r[0] * odts;
                         pri_rfz = r[1] * odts;
                         pni_rfz = r[2] * odts;
@@ -824,9 +853,9 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                     }
                     if (rc > kc::r_c1) {
                         const int id = (idx_c - 1) + ntb_c * (idx_tc - 1);
-                        pri_wfz = tb.tpi_qcfz[id] * odts;
+                        pri_wfz = kargs()->tables.tpi_qcfz[id] * odts;
                         pri_wfz = fmin(rc * odts, pri_wfz);
-                        pni_wfz = tb.tni_qcfz[id] * odts;
+                        pni_wfz = kargs()->tables.tni_qcfz[id] * odts;
                         pni_wfz = fmin(fmin(Nt_c * odts, pri_wfz / (2. * xm0i)), pni_wfz);
                         nc_m += pni_wfz;
                         ni_p += pni_wfz;
@@ -861,7 +890,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                             pni_ide = fmax(-ni * odts, pni_ide);
                         } else {
                             pri_ide = fmin(pri_ide, rate_max);
-                            const double frac = tb.tpi_ide[id];
+                            const double frac = kargs()->tables.tpi_ide[id];
                             prs_ide = (1.0 - frac) * pri_ide;
                             pri_ide = frac * pri_ide;
                         }
@@ -872,9 +901,9 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                             prs_iau = 0.;
                             pni_iau = 0.;
                         } else {
-                            prs_iau = tb.tps_iaus[id] * odts;
+                            prs_iau = kargs()->tables.tps_iaus[id] * odts;
                             prs_iau = fmin(ri * .99 * odts, prs_iau);
-                            pni_iau = tb.tni_iaus[id] * odts;
+                            pni_iau = kargs()->tables.tni_iaus[id] * odts;
                             pni_iau = fmin(ni * .95 * odts, pni_iau);
                         }
                         ni_m += pni_iau;
@@ -961,7 +990,8 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             }
 
             // inputs of block J: requested now, consumed after the limiters
-            const double nc1_raw = gnc[k], ni1_raw = gni[k], nr1_raw = gnr[k];
+            CArgs *kaJ = kargs();
+            const double nc1_raw = gptr(kaJ->nc, base)[k], ni1_raw = gptr(kaJ->ni, base)[k], nr1_raw = gptr(kaJ->nr, base)[k];
             const double qc1 = L(V_RC, k), qi1 = L(V_RI, k), qr1 = L(V_RR, k);
 
             // ---- I: conservation limiters, M:2297-2385 ----
@@ -1284,9 +1314,10 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             }
 
             // qv and the (inert) aerosol numbers are final here: blocks O-Q do not touch them
-            gqv[k] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
-            gnwfa[k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (nwfa1 + nwfaten * DT)));   // M:3628
-            gnifa[k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (nifa1 + 0. * DT)));       // M:3630
+            CArgs *kaN = kargs();
+            gptr(kaN->qv, base)[k] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
+            gptr(kaN->nwfa, base)[k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (nwfa1 + nwfaten * DT)));   // M:3628
+            gptr(kaN->nifa, base)[k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (nifa1 + 0. * DT)));       // M:3630
 
             L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
             L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
@@ -1298,7 +1329,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             }   // blocks K-N
         }
 
-        if (a.debug_stop == 3) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+        if (a.debug_stop == 3) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 3: fall speeds, M:3206-3354 ============
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
         double odz[NJ], orho_[NJ], tmp2[NJ];
@@ -1314,7 +1345,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = 0; dzv[j] = 1.; rhofv[j] = 0.;
             if (k >= nzu) continue;
             const double rho = L(V_RHO2, k);
-            dzv[j] = gdz[k];
+            dzv[j] = gptr(kargs()->dz, base)[k];
             odz[j] = 1. / dzv[j];
             orho_[j] = 1. / rho;
             tmp2[j] = L(V_TEMP2, k);
@@ -1501,12 +1532,12 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
         nstep_i = int(lround(1. / onstep_i));
         nstep_s = int(lround(1. / onstep_s));
         nstep_g = int(lround(1. / onstep_g));
-        if (a.nstep && lane == 0) {
-            a.nstep[col * 4 + 0] = nstep_r; a.nstep[col * 4 + 1] = nstep_i;
-            a.nstep[col * 4 + 2] = nstep_s; a.nstep[col * 4 + 3] = nstep_g;
+        if (int32_t *ns = kargs()->nstep; ns && lane == 0) {
+            ns[col * 4 + 0] = nstep_r; ns[col * 4 + 1] = nstep_i;
+            ns[col * 4 + 2] = nstep_s; ns[col * 4 + 3] = nstep_g;
         }
 
-        if (a.debug_stop == 4) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+        if (a.debug_stop == 4) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 4: sedimentation sweeps, M:3365-3578 ============
         double ppt_r = 0., ppt_s = 0., ppt_g = 0., ppt_i = 0.;
         {   // rain (never gated by l_sediment), M:3365-3399
@@ -1625,20 +1656,24 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             }
         }
         if (lane == 0) {                                     // precipitation is accumulated (INOUT, M:1172)
-            double *pp = a.ppt + col * 4;
+            double *pp = kargs()->ppt + col * 4;
             pp[0] = pp[0] + ppt_r;
             pp[1] = pp[1] + ppt_s;
             pp[2] = pp[2] + ppt_g;
             pp[3] = pp[3] + ppt_i;
         }
 
-        if (a.debug_stop == 5) { if (lane == 0) a.ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+        if (a.debug_stop == 5) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
         // ============ pass 5: blocks Q + R, M:3584-3686 ============
 #pragma unroll 1
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             if (k >= nzu) continue;
             const int f = pick(pst, j) & 31;
+            CArgs *ka = kargs();
+            gdouble *gqc = gptr(ka->qc, base), *gnc = gptr(ka->nc, base), *gqi = gptr(ka->qi, base),
+                    *gni = gptr(ka->ni, base), *gqr = gptr(ka->qr, base), *gnr = gptr(ka->nr, base),
+                    *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base), *gt = gptr(ka->t, base);
             const double rqc = gqc[k], rnc = gnc[k], rqi = gqi[k], rni = gni[k], rqr = gqr[k], rnr = gnr[k],
                          rqs = gqs[k], rqg = gqg[k], t1 = gt[k];       // one batch, cleaned below (block B)
             const double qc1 = (f & F_QC) ? rqc : 0.0, nc1 = (f & F_QC) ? rnc : 0.0;
@@ -1725,8 +1760,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             const double qg = qg1 + qgten * DT;
             gqg[k] = qg <= R1 ? 0.0 : qg;
         }
-        // (a wave's LDS image is private and its DS operations are ordered: no barrier between columns)
-    }
+    } while (false);
 }
 
 const char *column_kernel_name() { return "thompson_column_step"; }
@@ -1774,9 +1808,8 @@ hipError_t launch_column_step(const StepArgs &a, hipStream_t s)
 {
     if (a.ncol <= 0) return hipSuccess;
     if (a.nz < 2 || a.nz > 4 * WAVE) return hipErrorInvalidValue;
-    int64_t maxgrid = int64_t(1) << 20;
-    if (const char *e = getenv("KIDMP_GRID_CAP")) maxgrid = atoll(e) > 0 ? atoll(e) : maxgrid;   // tuning aid
-    const int grid = int(a.ncol < maxgrid ? a.ncol : maxgrid);
+    if (a.ncol > int64_t(0x7fffffff)) return hipErrorInvalidValue;   // one workgroup per column; 2^31 columns exceed HBM anyway
+    const int grid = int(a.ncol);
     const bool rates = a.rates != nullptr;
     // LDS per column = 21 slots * NL * 8 B; NL = 120 (KiD's nz) gives 8 resident columns per CU
     if (a.nz <= 64)  return launch_nj<1, 64>(a, rates, grid, s);
