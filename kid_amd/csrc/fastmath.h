@@ -1,0 +1,151 @@
+// fastmath.h -- fp64 log / exp / pow for the column kernel, sized to the arguments the scheme produces.
+//
+// The device math library's log, log10, exp, exp2 cost 60-100 fp64 instructions each because they carry
+// sub-ulp extended-precision paths and every special case.  The scheme only calls them on positive, finite,
+// normal arguments of moderate size, where a classic argument reduction plus one polynomial is enough:
+//
+//   ln m   on m in [sqrt(1/2), sqrt(2)):  s = f/(2+f), f = m-1;  ln(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
+//          with the degree-7 minimax R of the well-known fdlibm reduction (error < 1 ulp)
+//   2**r   on |r| <= 0.52: degree-13 Taylor polynomial in r (coefficients ln2^k/k!), even/odd split
+//   e**r   on |r| <= 0.36: degree-13 Taylor polynomial
+//
+// Every function here is within ~2 ulp of the correctly rounded result on its stated domain
+// (tests/test_fastmath.py measures this against 80-bit long double on the host build of this same header).
+// No tables, no divergent branches.  Host + device so that the accuracy test needs no GPU.
+#pragma once
+#include <cmath>
+
+#if defined(__HIPCC__)
+#define KFM_FN __host__ __device__ inline
+#else
+#define KFM_FN inline
+#endif
+
+namespace kidmp {
+namespace fm {
+
+constexpr double LN2 = 0.6931471805599453;
+constexpr double LN2_HI = 0.6931471803691238, LN2_LO = 1.9082149292705877e-10;   // LN2_HI has 21 trailing zero bits
+constexpr double INV_LN2 = 1.4426950408889634;
+constexpr double INV_LN10 = 0.4342944819032518;
+constexpr double LOG10_2 = 0.3010299956639812;
+constexpr double LOG2_10_HI = 3.321928094887362, LOG2_10_LO = 1.661617516973592e-16;
+constexpr double SQRT_HALF = 0.70710678118654757;
+
+// x = 2**e * m with m in [sqrt(1/2), sqrt(2)); x positive, finite, normal
+struct Split { double e, m; };
+KFM_FN Split split(double x)
+{
+    int e;
+    double m = std::frexp(x, &e);                        // m in [0.5, 1)
+    const bool low = m < SQRT_HALF;
+    m = low ? m * 2. : m;
+    e = low ? e - 1 : e;
+    return Split{double(e), m};
+}
+
+// ln(m) for m in [sqrt(1/2), sqrt(2))
+KFM_FN double ln_mant(double m)
+{
+    constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                     Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                     Lg7 = 1.479819860511658591e-01;
+    const double f = m - 1.;                             // exact
+    const double s = f / (2. + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * std::fma(w, std::fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * std::fma(w, std::fma(w, std::fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return f - (hfsq - s * (hfsq + R));
+}
+
+// 2**r for |r| <= 0.52 (relative error < 1 ulp)
+KFM_FN double exp2_small(double r)
+{
+    constexpr double c1 = 0.6931471805599453, c2 = 0.24022650695910072, c3 = 0.05550410866482158,
+                     c4 = 0.009618129107628477, c5 = 0.0013333558146428443, c6 = 0.0001540353039338161,
+                     c7 = 1.5252733804059841e-05, c8 = 1.321548679014431e-06, c9 = 1.01780860092397e-07,
+                     c10 = 7.054911620801123e-09, c11 = 4.4455382718708116e-10, c12 = 2.5678435993488206e-11,
+                     c13 = 1.3691488853904128e-12;
+    const double q = r * r;
+    // 2**r = 1 + r*(c1 + c3 q + c5 q^2 ...) + q*(c2 + c4 q + ...): two independent Horner chains in q
+    const double od = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, c13, c11), c9), c7), c5), c3), c1);
+    const double ev = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, c12, c10), c8), c6), c4), c2);
+    return 1. + std::fma(r, od, q * ev);
+}
+
+// e**r for |r| <= 0.36
+KFM_FN double exp_small(double r)
+{
+    constexpr double d2 = 0.5, d3 = 0.16666666666666666, d4 = 0.041666666666666664, d5 = 0.008333333333333333,
+                     d6 = 0.001388888888888889, d7 = 0.0001984126984126984, d8 = 2.48015873015873e-05,
+                     d9 = 2.7557319223985893e-06, d10 = 2.755731922398589e-07, d11 = 2.505210838544172e-08,
+                     d12 = 2.08767569878681e-09, d13 = 1.6059043836821613e-10;
+    const double q = r * r;
+    const double od = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, d13, d11), d9), d7), d5), d3);   // r^3 and up
+    const double ev = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, d12, d10), d8), d6), d4), d2);
+    return 1. + (r + q * std::fma(r, od, ev));
+}
+
+// ---- the libm entry points the scheme uses, on positive finite normal x / moderate arguments ----
+KFM_FN double log(double x)
+{
+    const Split p = split(x);
+    return std::fma(p.e, LN2_HI, std::fma(p.e, LN2_LO, ln_mant(p.m)));
+}
+KFM_FN double log10(double x)
+{
+    const Split p = split(x);
+    return std::fma(p.e, LOG10_2, ln_mant(p.m) * INV_LN10);
+}
+KFM_FN double exp(double x)                              // |x| < 700
+{
+    const double n = std::rint(x * INV_LN2);
+    const double r = std::fma(-n, LN2_LO, std::fma(-n, LN2_HI, x));
+    return std::ldexp(exp_small(r), int(n));
+}
+KFM_FN double exp10(double x)                            // |x| < 300
+{
+    const double hi = x * LOG2_10_HI;
+    const double lo = std::fma(x, LOG2_10_HI, -hi) + x * LOG2_10_LO;
+    const double n = std::rint(hi);
+    return std::ldexp(exp2_small((hi - n) + lo), int(n));
+}
+
+// ---- general powers: x**y = 2**(y*e + y*log2 m) ----
+// libm's pow carries an extended-precision logarithm because the error of log2(x) is multiplied by y and by
+// |log2 x| (up to ~40 here).  Splitting off the binary exponent removes that amplification: y*e is formed
+// exactly (product + fma residual), |log2 m| <= 1/2, the integer part n of the whole exponent goes to ldexp
+// and only the remainder |r| <= 1/2 through the polynomial.  For |y| <= 4.2 (every exponent of the scheme)
+// the result is within ~3 ulp of pow.  x must be positive, finite and normal.
+struct Log2Parts { double e, lm; };                      // log2(x) = e + lm/ln2, e integral, lm = ln(mantissa)
+KFM_FN Log2Parts log2_parts(double x)
+{
+    const Split p = split(x);
+    return Log2Parts{p.e, ln_mant(p.m)};
+}
+// 2**(t_hi + t_lo + y*log2(x)): t_hi + t_lo is an extra exponent known as an exact sum (0 for a bare power)
+KFM_FN double exp2_parts(const Log2Parts &l, double y, double t_hi, double t_lo)
+{
+    const double p_hi = y * l.e;
+    const double p_lo = std::fma(y, l.e, -p_hi);         // y*e = p_hi + p_lo exactly
+    const double s = p_hi + t_hi;                        // two-sum: s + s_lo = p_hi + t_hi exactly
+    const double bb = s - p_hi;
+    const double s_lo = (p_hi - (s - bb)) + (t_hi - bb);
+    const double frac = ((s_lo + p_lo) + t_lo) + (y * INV_LN2) * l.lm;   // everything but s, |frac| <= ~2.2
+    const double n = std::rint(s + frac);
+    const double r = (s - n) + frac;
+    return std::ldexp(exp2_small(r), int(n));
+}
+KFM_FN double pow(double x, double y) { return exp2_parts(log2_parts(x), y, 0., 0.); }
+// 10**la * x**y in one exponential (the a_*smo2**b_ pattern of the Field et al. moments, M:1572-1574)
+KFM_FN double pow10_times_pow(double la, const Log2Parts &l, double y)
+{
+    const double t_hi = la * LOG2_10_HI;
+    const double t_lo = std::fma(la, LOG2_10_HI, -t_hi) + la * LOG2_10_LO;
+    return exp2_parts(l, y, t_hi, t_lo);
+}
+
+}  // namespace fm
+}  // namespace kidmp

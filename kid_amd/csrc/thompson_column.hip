@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "thompson_column.h"
+#include "fastmath.h"
 #include "thompson_consts_gen.h"   // kc::*, generated at build time by gen_consts.cpp
 
 #include <cstdlib>
@@ -203,44 +204,12 @@ __device__ inline double root3(double x) { return cbrt(x); }                    
 __device__ inline double root4(double x) { return sqrt(sqrt(x)); }                 // **oge1 = 1/(bm_g+1)
 __device__ inline double root6(double x) { return sqrt(cbrt(x)); }                 // **(1./6.), M:1701
 
-// ---- general powers: x**y = 2**(y*e + y*log2(m)),  x = 2**e * m,  m in [sqrt(1/2), sqrt(2)) ----
-// libm's pow spends most of its ~250 fp64 instructions on an extended-precision logarithm because the
-// error of log2(x) is multiplied by y and by |log2 x| (up to ~40 here).  Splitting off the binary exponent
-// removes that amplification: y*e is formed exactly (product + fma residual), |log2 m| <= 1/2, and only the
-// small remainder r goes through exp2.  For |y| <= 4.2 (every exponent of the scheme) the result is within
-// ~3 ulp of pow (<= 2 ulp for |y| < 1) at ~100 instructions.  x must be positive and finite.
-struct Log2Parts { double e, lg; };                      // log2(x) = e + lg, e integral, |lg| <= 0.5
-__device__ inline Log2Parts log2_parts(double x)
-{
-    int e;
-    double m = frexp(x, &e);                             // m in [0.5, 1)
-    if (m < 0.70710678118654757) { m *= 2.; e -= 1; }    // m in [sqrt(1/2), sqrt(2))
-    Log2Parts p;
-    p.e = double(e);
-    p.lg = log2(m);
-    return p;
-}
-// 2**(t_hi + t_lo + y*log2(x)): t_hi + t_lo is an extra exponent known as an exact sum (0 for a bare power)
-__device__ inline double exp2_parts(const Log2Parts &l, double y, double t_hi, double t_lo)
-{
-    const double p_hi = y * l.e;
-    const double p_lo = fma(y, l.e, -p_hi);              // y*e = p_hi + p_lo exactly
-    const double s = p_hi + t_hi;                        // two-sum: s + s_lo = p_hi + t_hi exactly
-    const double bb = s - p_hi;
-    const double s_lo = (p_hi - (s - bb)) + (t_hi - bb);
-    const double n = rint(s);
-    const double r = (s - n) + (((s_lo + p_lo) + t_lo) + y * l.lg);
-    return ldexp(exp2(r), int(n));
-}
-__device__ inline double fpow(double x, double y) { return exp2_parts(log2_parts(x), y, 0., 0.); }
-// 10**la * x**y in one exponential (the a_*smo2**b_ pattern of the Field et al. moments, M:1572-1574)
-__device__ inline double pow10_times_pow(double la, const Log2Parts &l, double y)
-{
-    const double L10_hi = 3.3219280948873622, L10_lo = 1.6616175169735920e-16;   // log2(10)
-    const double t_hi = la * L10_hi;
-    const double t_lo = fma(la, L10_hi, -t_hi) + la * L10_lo;
-    return exp2_parts(l, y, t_hi, t_lo);
-}
+// ---- log / exp / general powers: fastmath.h (argument-range-specific, ~2 ulp, about half the instructions
+//      of the device math library) ----
+using fm::Log2Parts;
+using fm::log2_parts;
+using fm::pow10_times_pow;
+__device__ inline double fpow(double x, double y) { return fm::pow(x, y); }
 
 // ---------------- scalar helpers ----------------
 // Decade index of M:1763-1771 and its seven siblings:
@@ -302,7 +271,7 @@ __device__ inline double rsif(double P, double T)
 // (<= 3 ulp from libm pow) at a third of pow's cost.
 __device__ inline double diffusivity(double temp, double pres)
 {
-    return 2.11E-5 * exp(1.94 * log(temp / 273.15)) * (101325. / pres);
+    return 2.11E-5 * fm::exp(1.94 * fm::log(temp / 273.15)) * (101325. / pres);
 }
 
 __device__ inline double visc_air(double tempc)          // M:1524-1528
@@ -326,10 +295,10 @@ __device__ inline double snow_moment(const Log2Parts &lsmo2, double tc0, double 
 // graupel intercept before the running minimum, M:1639-1647
 __device__ inline double graupel_N0(bool use_rain, double mvd_r, double rg)
 {
-    const double xslw1 = use_rain ? 4.01 + log10(mvd_r) : 0.01;
-    const double ygra1 = 4.31 + log10(fmax(5.E-5, rg));
+    const double xslw1 = use_rain ? 4.01 + fm::log10(mvd_r) : 0.01;
+    const double ygra1 = 4.31 + fm::log10(fmax(5.E-5, rg));
     const double zans1 = 3.1 + (100. / (300. * xslw1 * ygra1 / (10. / xslw1 + 1. + 0.25 * ygra1) + 30. + 10. * ygra1));
-    const double N0 = exp10(zans1);
+    const double N0 = fm::exp10(zans1);
     return fmax(gonv_min, fmin(N0, gonv_max));
 }
 
@@ -664,7 +633,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
 
             // ---- G: warm-rain terms, M:1676-1726 ----
             if (L_qr && mvd_r > D0r) {
-                const double Ef_rr = 1.0 - exp(2300.0 * (mvd_r - 1950.0E-6));
+                const double Ef_rr = 1.0 - fm::exp(2300.0 * (mvd_r - 1950.0E-6));
                 pnr_rcr = Ef_rr * 2.0 * nr * rr;
                 nr_m += pnr_rcr;
             }
@@ -695,7 +664,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 nc_m += pnc_wau;
             }
             if (L_qr && mvd_r > D0r && mvd_c > D0c) {        // accretion, M:1715-1726
-                int idx = 1 + int(nbins * log(mvd_r / kc::Dr1) / log(kc::Drn / kc::Dr1));
+                int idx = 1 + int(nbins * fm::log(mvd_r / kc::Dr1) / kc::log_Drn_Dr1);
                 idx = idx < nbins ? idx : nbins;
                 idx = idx > 1 ? idx : 1;
                 int jc = int(mvd_c * 1.E6);
@@ -760,7 +729,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                     int jc = int(mvd_c * 1.E6);
                     jc = jc < 1 ? 1 : (jc > nbins ? nbins : jc);
                     if (xDs > D0s) {
-                        int idx = 1 + int(nbins * log(xDs / kc::Ds1) / log(kc::Dsn / kc::Ds1));
+                        int idx = 1 + int(nbins * fm::log(xDs / kc::Ds1) / kc::log_Dsn_Ds1);
                         idx = idx < nbins ? idx : nbins;
                         idx = idx > 1 ? idx : 1;
                         const double Ef_sw = kargs()->tables.t_Efsw[(idx - 1) + nbins * (jc - 1)];
@@ -775,7 +744,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                         const double stoke_g = mvd_c * mvd_c * vtg * rho_w / (9. * visco * xDg);
                         if (xDg > D0g) {
                             double Ef_gw = 0.;
-                            if (stoke_g >= 0.4 && stoke_g <= 10.) Ef_gw = 0.55 * log10(2.51 * stoke_g);
+                            if (stoke_g >= 0.4 && stoke_g <= 10.) Ef_gw = 0.55 * fm::log10(2.51 * stoke_g);
                             else if (stoke_g < 0.4)               Ef_gw = 0.0;
                             else if (stoke_g > 10)                Ef_gw = 0.77;
                             const double ig9 = cube(ilamg) * ig_bv;          // ilamg**cge(9), cge(9) = 3 + bv_g
@@ -868,7 +837,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
 
                     // Cooper nucleation, M:2090-2101
                     if ((ssati >= 0.25) || (ssatw > eps && temp < 253.15)) {
-                        const double xnc = fmin(250.E3, TNO * exp(ATO * (T_0 - temp)));
+                        const double xnc = fmin(250.E3, TNO * fm::exp(ATO * (T_0 - temp)));
                         const double xni = ni + (pni_rfz + pni_wfz) * DT;
                         pni_inu = 0.5 * (xnc - xni + fabs(xnc - xni)) * odts;
                         pri_inu = fmin(rate_max, xm0i * pni_inu);
@@ -962,7 +931,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                         prr_sml = (tempc * tcond - lvap0 * diffu * delQvs) * (kc::t1_qs_me * smo1 + kc::t2_qs_me * rhof2 * vsc2 * smof);
                         prr_sml = prr_sml + 4218. * olfus * tempc * (prr_rcs + prs_scw);
                         prr_sml = fmin(rs * odts, fmax(0., prr_sml));
-                        pnr_sml = smo0 / rs * prr_sml * exp10(-0.25 * tempc);
+                        pnr_sml = smo0 / rs * prr_sml * fm::exp10(-0.25 * tempc);
                         pnr_sml = fmin(smo0 * odts, pnr_sml);
                         nr_p += pnr_sml;
                         if (ssati < 0.) {
@@ -974,7 +943,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                         const double ig10 = ilamg * ilamg;
                         prr_gml = (tempc * tcond - lvap0 * diffu * delQvs) * N0_g * (kc::t1_qg_me * ig10 + kc::t2_qg_me * rhof2 * vsc2 * ig11);
                         prr_gml = fmin(rg * odts, fmax(0., prr_gml));
-                        pnr_gml = N0_g * kc::cgg[1] * ilamg / rg * prr_gml * exp10(-0.5 * tempc);
+                        pnr_gml = N0_g * kc::cgg[1] * ilamg / rg * prr_gml * fm::exp10(-0.5 * tempc);
                         nr_p += pnr_gml;
                         if (ssati < 0.) {
                             prg_gde = C_cube * t1_subl * diffu * ssati * rvs * N0_g * (kc::t1_qg_sd * ig10 + kc::t2_qg_sd * vsc2 * rhof2 * ig11);
@@ -1226,7 +1195,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             if ((ssatw > eps) || (ssatw < -eps && (f2 & F_QC))) {
                 double clap = (qv - qvs) / (1. + lvt2 * qvs);
                 for (int n = 0; n < 3; ++n) {
-                    const double ex = exp(lvt2 * clap);
+                    const double ex = fm::exp(lvt2 * clap);
                     const double fcd = qvs * ex - qv + clap;
                     const double dfcd = qvs * lvt2 * ex + 1.;
                     clap = clap - fcd / dfcd;

@@ -1,0 +1,29 @@
+"""Accuracy of kid_amd/csrc/fastmath.h (the column kernel's log/exp/pow) on the host build of the same header.
+
+The header is plain C++ (host + device); tests/native/fastmath_check.cpp evaluates every function over the
+argument ranges the scheme produces and reports the maximum error in ulps against 80-bit long double.
+No reference file is involved: these functions replace libm calls of the reference (DLOG, EXP, 10.**x, x**y
+all over M:1545-3354) and the bound asserted here is what DESIGN.md quotes.
+"""
+import os
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BOUNDS = {  # max ulp error allowed over the sampled domain
+    "ln_mant": 1.0, "exp2_small": 1.5, "log": 1.5, "log10": 2.0, "exp": 1.5, "exp10": 1.5,
+    "pow": 4.0, "pow10_times_pow": 4.0,
+}
+
+
+def test_fastmath_ulp_bounds():
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "fmcheck")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "kid_amd", "csrc"),
+                               os.path.join(ROOT, "tests", "native", "fastmath_check.cpp"), "-o", exe])
+        out = subprocess.check_output([exe, "300000"], text=True)
+    got = {k: float(v) for k, v in (line.split() for line in out.strip().splitlines())}
+    assert set(got) == set(BOUNDS)
+    for name, bound in BOUNDS.items():
+        assert got[name] <= bound, f"{name}: {got[name]} ulp > {bound}"
