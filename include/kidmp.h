@@ -122,6 +122,18 @@ int kidmp_load_table_cache(kidmp_ctx *ctx, const char *dir);
 int kidmp_cache_write_file(const char *path, int32_t ntab, const double *const *tabs, int64_t n_each);
 int kidmp_cache_read_file(const char *path, int32_t ntab, double *const *tabs, int64_t n_each);
 
+/* Diagnostics: evaluate one of the column kernel's own fp64 math helpers (kid_amd/csrc/fastmath.h, which stand
+ * in for the reference's DLOG / ALOG10 / EXP / 10.**x / x**y / SQRT / x**(1./3.)) on the device, elementwise on
+ * host arrays: out[i] = fn(x[i]) (fn(x[i], y[i]) for KIDMP_MATH_POW; y is read but ignored otherwise). */
+#define KIDMP_MATH_LOG    0
+#define KIDMP_MATH_LOG10  1
+#define KIDMP_MATH_EXP    2
+#define KIDMP_MATH_EXP10  3
+#define KIDMP_MATH_SQRT   4
+#define KIDMP_MATH_CBRT   5
+#define KIDMP_MATH_POW    6
+int kidmp_math_probe(kidmp_ctx *ctx, int32_t fn, int64_t n, const double *x, const double *y, double *out);
+
 /* Seconds spent in table construction during kidmp_init (host wall clock). */
 double kidmp_init_seconds(const kidmp_ctx *ctx);
 

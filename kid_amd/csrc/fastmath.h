@@ -88,6 +88,46 @@ KFM_FN double exp_small(double r)
     return 1. + (r + q * std::fma(r, od, ev));
 }
 
+// sqrt(x) for positive, finite, normal x well inside the exponent range (no rescaling, no 0/inf cases):
+// reciprocal-square-root seed, one Goldschmidt step and two residual corrections (the iteration the compiler's
+// own fp64 sqrt expansion uses, minus its range handling).  <= 1 ulp.
+KFM_FN double sqrt_pos(double x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);            // v_rsq_f64
+#else
+    const double y = double(1.0f / std::sqrt(float(x))); // host stand-in with a seed of comparable quality
+#endif
+    const double g0 = x * y, h0 = 0.5 * y;
+    const double r0 = std::fma(-h0, g0, 0.5);
+    const double g1 = std::fma(g0, r0, g0), h1 = std::fma(h0, r0, h0);
+    const double d0 = std::fma(-g1, g1, x);
+    const double g2 = std::fma(d0, h1, g1);
+    const double d1 = std::fma(-g2, g2, x);
+    return std::fma(d1, h1, g2);
+}
+
+// cbrt(x) for positive x in [1e-37, 1e37] (the fp32 range: the seed is taken in fp32):
+//   y0 = 2**(-log2(x)/3) from the fp32 log2/exp2 units (>= 18 bits), one cubically convergent step towards
+//   x**(-1/3) (e = 1 - x y^3; y <- y (1 + e/3 + 2 e^2/9)), c = x y^2, one Newton correction of c.  <= 1 ulp.
+KFM_FN double cbrt_pos(double x)
+{
+    const float xf = float(x);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float yf = __builtin_amdgcn_exp2f(-0.33333334f * __builtin_amdgcn_logf(xf));   // v_exp_f32, v_log_f32
+#else
+    const float yf = std::exp2(-0.33333334f * std::log2(xf));
+#endif
+    double y = double(yf);
+    const double t0 = y * y;
+    const double e = std::fma(-x, t0 * y, 1.);
+    y = std::fma(y * e, std::fma(e, 2. / 9., 1. / 3.), y);
+    const double t = y * y;
+    const double c = x * t;
+    const double r = std::fma(-(c * c), c, x);
+    return std::fma(r, t * (1. / 3.), c);
+}
+
 // ---- the libm entry points the scheme uses, on positive finite normal x / moderate arguments ----
 KFM_FN double log(double x)
 {

@@ -17,6 +17,7 @@
 #include "thompson_host_init.h"
 #include "thompson_tables.h"
 #include "table_cache.h"
+#include "fastmath.h"
 
 using namespace kidmp;
 
@@ -146,6 +147,24 @@ std::vector<Named> const_dir(const kidmp_ctx *c)
         {"r_c", b.r_c, ntb_c}, {"r_i", b.r_i, ntb_i}, {"r_r", b.r_r, ntb_r}, {"r_g", b.r_g, ntb_g},
         {"r_s", b.r_s, ntb_s}, {"N0r_exp", b.N0r_exp, ntb_r1}, {"N0g_exp", b.N0g_exp, ntb_g1}, {"Nt_i", b.Nt_i, ntb_i1},
     };
+}
+
+// device evaluation of the kernel's math helpers (fastmath.h) for the accuracy test
+__global__ void k_math_probe(int fn, int64_t n, const double *x, const double *y, double *out)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r = 0.;
+    switch (fn) {
+    case KIDMP_MATH_LOG:   r = fm::log(x[i]); break;
+    case KIDMP_MATH_LOG10: r = fm::log10(x[i]); break;
+    case KIDMP_MATH_EXP:   r = fm::exp(x[i]); break;
+    case KIDMP_MATH_EXP10: r = fm::exp10(x[i]); break;
+    case KIDMP_MATH_SQRT:  r = fm::sqrt_pos(x[i]); break;
+    case KIDMP_MATH_CBRT:  r = fm::cbrt_pos(x[i]); break;
+    case KIDMP_MATH_POW:   r = fm::pow(x[i], y[i]); break;
+    }
+    out[i] = r;
 }
 
 int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const void *const *ptrs, int nptr)
@@ -316,6 +335,25 @@ int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n, const double *qv, c
     hipLaunchKernelGGL(k_default_aerosols, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, (hipStream_t)stream, n,
                        ctx->hc.Nt_c, qv, t, p, nc, nwfa, nifa);
     HIPTRY(ctx, hipGetLastError());
+    return KIDMP_OK;
+}
+
+int kidmp_math_probe(kidmp_ctx *ctx, int32_t fn, int64_t n, const double *x, const double *y, double *out)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (n < 0 || !x || !y || !out || fn < 0 || fn > KIDMP_MATH_POW) return fail(ctx, KIDMP_EINVAL, "kidmp_math_probe: bad argument");
+    if (n == 0) return KIDMP_OK;
+    double *d = nullptr;
+    HIPTRY(ctx, hipMalloc(&d, size_t(n) * 3 * sizeof(double)));
+    hipError_t e = hipMemcpy(d, x, size_t(n) * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + n, y, size_t(n) * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_math_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, fn, n, d, d + n, d + 2 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d + 2 * n, size_t(n) * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIPTRY(ctx, e);
     return KIDMP_OK;
 }
 

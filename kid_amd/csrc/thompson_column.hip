@@ -198,11 +198,11 @@ __device__ inline double cube(double x) { return x * x * x; }                   
 __device__ inline double pw4(double x) { const double s = x * x; return s * s; }   // **cre(1), cre(3), cre(9), cge(1)
 __device__ inline double pw5(double x) { const double s = x * x; return s * s * x; }           // **cre(6)
 __device__ inline double pw7(double x) { const double s = x * x; return s * s * s * x; }       // **cre(8)
-__device__ inline double pw2h(double x) { return x * x * sqrt(x); }                // **cre(12) = 2.5
-__device__ inline double pw3h(double x) { return x * x * x * sqrt(x); }            // **cre(7)  = 3.5
-__device__ inline double root3(double x) { return cbrt(x); }                       // **obmr, **obmi, **obmg
-__device__ inline double root4(double x) { return sqrt(sqrt(x)); }                 // **oge1 = 1/(bm_g+1)
-__device__ inline double root6(double x) { return sqrt(cbrt(x)); }                 // **(1./6.), M:1701
+__device__ inline double pw2h(double x) { return x * x * fm::sqrt_pos(x); }                // **cre(12) = 2.5
+__device__ inline double pw3h(double x) { return x * x * x * fm::sqrt_pos(x); }            // **cre(7)  = 3.5
+__device__ inline double root3(double x) { return fm::cbrt_pos(x); }                       // **obmr, **obmi, **obmg
+__device__ inline double root4(double x) { return fm::sqrt_pos(fm::sqrt_pos(x)); }                 // **oge1 = 1/(bm_g+1)
+__device__ inline double root6(double x) { return fm::sqrt_pos(fm::cbrt_pos(x)); }                 // **(1./6.), M:1701
 
 // ---- log / exp / general powers: fastmath.h (argument-range-specific, ~2 ulp, about half the instructions
 //      of the device math library) ----
@@ -563,10 +563,10 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
 
             // cheap thermodynamics of block C recomputed here, M:1504-1532
             const double tempc = temp - 273.15;
-            const double rhof = sqrt(rho_not / rho);
-            const double rhof2 = sqrt(rhof);
+            const double rhof = fm::sqrt_pos(rho_not / rho);
+            const double rhof2 = fm::sqrt_pos(rhof);
             const double visco = visc_air(tempc);
-            const double vsc2 = sqrt(rho / visco);
+            const double vsc2 = fm::sqrt_pos(rho / visco);
             const double tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
 
             // ---- D: snow moments, M:1546-1627 ----
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 if (L_qg) {
                     // ilamg**bv_g is the one general power; cge(9) = 3 + bv_g, cge(10) = 2, cge(11) = 2.5 + bv_g/2
                     ig_bv = fpow(ilamg, bv_g);
-                    ig11 = ilamg * ilamg * sqrt(ilamg * ig_bv);
+                    ig11 = ilamg * ilamg * fm::sqrt_pos(ilamg * ig_bv);
                 }
             }
 
@@ -1140,14 +1140,14 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             double tempc = temp - 273.15;
             double qv = fmax(1.E-10, qv1 + DT * qvten);
             double rho = 0.622 * pres / (Rgas * temp * (qv + 0.622));
-            double rhof = sqrt(rho_not / rho);
-            double rhof2 = sqrt(rhof);
+            double rhof = fm::sqrt_pos(rho_not / rho);
+            double rhof2 = fm::sqrt_pos(rhof);
             double qvs = rslf(pres, temp);
             double ssatw = qv / qvs - 1.;
             if (fabs(ssatw) < eps) ssatw = 0.0;
             double diffu = diffusivity(temp, pres);
             double visco = visc_air(tempc);
-            double vsc2 = sqrt(rho / visco);
+            double vsc2 = fm::sqrt_pos(rho / visco);
             double lvap = lvap0 + (2106.0 - 4218.0) * tempc;
             double tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
             double ocp = 1. / (Cp * (1. + 0.887 * qv));
@@ -1231,11 +1231,11 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 tempc = temp - 273.15;
                 otemp = 1. / temp;
                 orho = 1. / rho;
-                rhof = sqrt(rho_not * orho);
-                rhof2 = sqrt(rhof);
+                rhof = fm::sqrt_pos(rho_not * orho);
+                rhof2 = fm::sqrt_pos(rhof);
                 diffu = diffusivity(temp, pres);
                 visco = visc_air(tempc);
-                vsc2 = sqrt(rho / visco);
+                vsc2 = fm::sqrt_pos(rho / visco);
                 lvap = lvap0 + (2106.0 - 4218.0) * tempc;
                 tcond = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
                 ocp = 1. / (Cp * (1. + 0.887 * qv));
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             orho_[j] = 1. / rho;
             tmp2[j] = L(V_TEMP2, k);
             const double rr = L(V_RR2, k);
-            const double rhof = sqrt(rho_not / rho);
+            const double rhof = fm::sqrt_pos(rho_not / rho);
             rhofv[j] = rhof;
             if (rr > R1) {                                   // M:3221-3233
                 ok[j] = 1;

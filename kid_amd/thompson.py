@@ -76,6 +76,8 @@ def load_library():
     L.kidmp_default_aerosols_device.argtypes = [_vp, C.c_int64] + [_vp] * 6 + [_vp]
     L.kidmp_reduce_ppt_device.restype = C.c_int
     L.kidmp_reduce_ppt_device.argtypes = [_vp, C.c_int64, _vp, _vp, _vp]
+    L.kidmp_math_probe.restype = C.c_int
+    L.kidmp_math_probe.argtypes = [_vp, C.c_int32, C.c_int64, _dp, _dp, _dp]
     L.kidmp_get_table.restype = C.c_int64
     L.kidmp_get_table.argtypes = [_vp, C.c_char_p, _dp, C.c_int64]
     L.kidmp_get_const.restype = C.c_int64
@@ -209,6 +211,17 @@ class ThompsonMP:
         return out
 
     # ---- introspection for parity tests ----
+    MATH_FUNCS = ("log", "log10", "exp", "exp10", "sqrt", "cbrt", "pow")
+
+    def math_probe(self, fn, x, y=None):
+        """Evaluate one of the column kernel's fp64 math helpers (csrc/fastmath.h) on the device, elementwise."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(x if y is None else y, dtype=np.float64)
+        out = np.empty_like(x)
+        self._check(load_library().kidmp_math_probe(self._h, self.MATH_FUNCS.index(fn), x.size, _np_ptr(x), _np_ptr(y),
+                                                    _np_ptr(out)))
+        return out
+
     def table(self, name, shape=None):
         L = load_library()
         n = self._check(L.kidmp_get_table(self._h, name.encode(), None, 0))

@@ -20,13 +20,16 @@ int main(int argc, char **argv)
     std::mt19937_64 rng(12345);
     std::uniform_real_distribution<double> U(0., 1.);
     namespace fm = kidmp::fm;
-    double e_log = 0, e_log10 = 0, e_exp = 0, e_exp10 = 0, e_pow = 0, e_p10 = 0, e_lm = 0, e_e2 = 0;
+    double e_sqrt = 0, e_cbrt = 0, e_log = 0, e_log10 = 0, e_exp = 0, e_exp10 = 0, e_pow = 0, e_p10 = 0, e_lm = 0, e_e2 = 0;
     for (long i = 0; i < n; ++i) {
         // positive normal arguments over 1e-45 .. 1e+25 (mixing ratios, numbers, diameters, slopes)
         const double lx = -45. + 70. * U(rng);
         const double x = std::pow(10., lx) * (1. + U(rng));
         e_log = std::fmax(e_log, ulp_err(fm::log(x), logl((long double)x)));
         e_log10 = std::fmax(e_log10, ulp_err(fm::log10(x), log10l((long double)x)));
+        const double xc = std::pow(10., -36. + 72. * U(rng)) * (1. + U(rng));     // cbrt/sqrt domain
+        e_cbrt = std::fmax(e_cbrt, ulp_err(fm::cbrt_pos(xc), cbrtl((long double)xc)));
+        e_sqrt = std::fmax(e_sqrt, ulp_err(fm::sqrt_pos(xc), sqrtl((long double)xc)));
         const double m = 0.70710678118654757 + U(rng) * (1.4142135623730949 - 0.70710678118654757);
         e_lm = std::fmax(e_lm, ulp_err(fm::ln_mant(m), logl((long double)m)));
         const double r = -0.52 + 1.04 * U(rng);
@@ -42,7 +45,7 @@ int main(int argc, char **argv)
         e_p10 = std::fmax(e_p10, ulp_err(fm::pow10_times_pow(la, fm::log2_parts(xs), yb),
                                         powl(10.L, (long double)la) * powl((long double)xs, (long double)yb)));
     }
-    printf("ln_mant %.3f\nexp2_small %.3f\nlog %.3f\nlog10 %.3f\nexp %.3f\nexp10 %.3f\npow %.3f\npow10_times_pow %.3f\n",
-           e_lm, e_e2, e_log, e_log10, e_exp, e_exp10, e_pow, e_p10);
+    printf("sqrt_pos %.3f\ncbrt_pos %.3f\nln_mant %.3f\nexp2_small %.3f\nlog %.3f\nlog10 %.3f\nexp %.3f\nexp10 %.3f\npow %.3f\npow10_times_pow %.3f\n",
+           e_sqrt, e_cbrt, e_lm, e_e2, e_log, e_log10, e_exp, e_exp10, e_pow, e_p10);
     return 0;
 }
