@@ -16,7 +16,9 @@
  *   - Every function returns 0 on success or a negative KIDMP_E* code; it
  *     never aborts and never throws.  kidmp_last_error() gives the text.
  *   - One context per process and device; calls on one context are
- *     serialised by the caller (the reference is single-threaded, M:386-430).
+ *     serialised by the caller (the reference is single-threaded, M:386-430),
+ *     and its asynchronous launches must not overlap on the device (enqueue
+ *     them on one stream): a context owns one work buffer.
  */
 #ifndef KIDMP_H
 #define KIDMP_H

@@ -35,6 +35,9 @@ struct kidmp_ctx {
     double *d_stage = nullptr;
     size_t stage_bytes = 0;
     hipStream_t stream = nullptr;
+    // [ncol][nz] work profile of the column kernel (StepArgs::scratch), grown on demand
+    double *d_scratch = nullptr;
+    size_t scratch_elems = 0;
     int debug_stop = 0;
     int cslot = -1;
 };
@@ -247,6 +250,7 @@ void kidmp_finalize(kidmp_ctx *c)
     if (c->d_consts) (void)hipFree(c->d_consts);
     if (c->d_bins) (void)hipFree(c->d_bins);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     give_slot(c->cslot);
     delete c;
@@ -272,6 +276,16 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     a.cslot = ctx->cslot; a.tables = ctx->tables;
     a.ncol = ncol; a.nz = nz; a.dt = dt;
     a.debug_stop = ctx->debug_stop;
+    if (ncol == 0) return KIDMP_OK;
+    const size_t need = size_t(ncol) * size_t(nz);
+    if (need > ctx->scratch_elems) {                     // hipFree waits for launches still using the old buffer
+        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+        ctx->d_scratch = nullptr;
+        ctx->scratch_elems = 0;
+        HIPTRY(ctx, hipMalloc((void **)&ctx->d_scratch, need * sizeof(double)));
+        ctx->scratch_elems = need;
+    }
+    a.scratch = ctx->d_scratch;
     HIPTRY(ctx, launch_column_step(a, (hipStream_t)stream));
     return KIDMP_OK;
 }

@@ -17,6 +17,7 @@ struct StepArgs {
     double *ppt;          // [ncol][4] rain, snow, graupel, ice (accumulated, M:1172)
     double *rates;        // nullptr or [ncol][36][nz]
     int32_t *nstep;       // nullptr or [ncol][4] rain, ice, snow, graupel
+    double *scratch;      // [ncol][nz] work profile owned by the context (block-K rain mvd, pass 1 -> pass 3)
     int32_t cslot;        // slot of this context's Consts in constant memory (upload_consts)
     Tables tables;
     int64_t ncol;

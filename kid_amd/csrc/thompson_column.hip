@@ -42,10 +42,6 @@ namespace kidmp {
 namespace {
 
 constexpr int WAVE = 64;
-#ifndef KIDMP_WPB
-#define KIDMP_WPB 1
-#endif
-constexpr int WPB = KIDMP_WPB;          // waves (= columns) per workgroup; 2 measured equal to 1 on MI355X
 
 // ---------------- wave primitives ----------------
 // Cross-lane work stays on the VALU: DPP row shifts inside the four 16-lane rows, v_readlane to
@@ -364,11 +360,21 @@ __device__ inline CArgs *kargs()
 
 // NJ = level groups per lane (ceil(nz/64)); NL = LDS stride per slot (>= nz), a compile-time
 // constant so that every slot address is "one VGPR (8k) + immediate offset (slot*NL*8)".
-template <int NJ, int NL, bool RATES>
-__global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepArgs a)
+// CPW = columns (= waves) per workgroup.  Each wave owns one column for the passes with a vertical dependency
+// (0: block E scan, 3: fall-speed scans, 4: sedimentation, 5).  The pointwise pass 1 (blocks D-N, ~60 % of the
+// instructions) is shared out differently: the CPW columns of the workgroup are cut into bands of 64/CPW levels
+// and one wave pass handles the same band of all CPW columns.  Lanes of a wave then sit at the same altitude,
+// i.e. in the same microphysical regime (warm rain / melting layer / mixed phase / ice), so far fewer lanes idle
+// in the regime-specific branches than when a wave spans 64 consecutive levels of one column.
+template <int NJ, int NL, int CPW, bool RATES>
+__global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepArgs a)
 {
-    __shared__ double Lsh[WPB][NSLOT * NL];          // one private [NSLOT][NL] image per wave (= per column)
-    double *const Lw = Lsh[threadIdx.x / WAVE];
+    constexpr int BL = WAVE / CPW;                   // levels per band
+    __shared__ double Lsh[CPW][NSLOT * NL];          // one [NSLOT][NL] image per column
+    __shared__ int s_alive[CPW];                     // column takes part in pass 1 (exists and has microphysics)
+    __shared__ int s_next;                           // pass 1: next band to hand out
+    const int wv = CPW > 1 ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE) : 0;
+    double *const Lw = Lsh[wv];
 #define L(slot, k) Lw[(slot) * NL + (k)]
 
     const Consts &c = g_consts[a.cslot];
@@ -382,21 +388,25 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
     const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
     const double Nt_c = c.Nt_c;
 
-    // One column per wave, one launch covers all columns (grid = ncol / WPB workgroups).  Deliberately not a
+    // One column per wave, one launch covers all columns (grid = ncol / CPW workgroups).  Deliberately not a
     // grid-stride loop: a loop invites the compiler to hoist every column-invariant scalar (dt-derived values,
     // the debug switches, lane predicates) to kernel entry and keep them in SGPRs across the whole body,
-    // and those are the SGPRs it then spills.  `continue` below leaves the column.
-    const int64_t col = int64_t(blockIdx.x) * WPB + threadIdx.x / WAVE;
-    if (col >= a.ncol) return;
-    do {
-        if (a.debug_stop == 9) continue;                     // profiling aid: launch floor
-        const int64_t base = col * int64_t(nz);
+    // and those are the SGPRs it then spills.
+    const int64_t col0 = int64_t(blockIdx.x) * CPW;          // first column of the workgroup
+    const int64_t col = col0 + wv;
+    bool alive = col < a.ncol;                               // wave-uniform; false: only helps out in pass 1
+    {
+        if (a.debug_stop == 9) return;                       // profiling aid: launch floor
+        const int64_t base = col * int64_t(nz), base0 = col0 * int64_t(nz);
         // the 12 state profiles are read and written in place (no __restrict__); bases are wave-uniform and
         // rebuilt from the kernel arguments at each use (see kargs())
         // ============ pass 0: blocks B + C, M:1387-1533 ============
         int pst[NJ];              // per level group: bits 0-4 L_q* of block B, bits 8-12 L_q* of block K, bit 16 T >= 270.65
         double mvdB[NJ], rgB[NJ];
         bool any_micro = false;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { pst[j] = 0; mvdB[j] = 0.; rgB[j] = R1; }
+        if (alive) {
         // all first-touch HBM loads of the column are issued together (one round trip):
         double i_t[NJ], i_qv[NJ], i_p[NJ], i_qc[NJ], i_qi[NJ], i_qr[NJ], i_qs[NJ], i_qg[NJ], i_ni[NJ], i_nr[NJ];
         {
@@ -508,11 +518,11 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                     for (int r = 0; r < KIDMP_NRATES_; ++r) grates[int64_t(r) * nz + k] = 0.;
             }
             if (ka->nstep && lane < 4) ka->nstep[col * 4 + lane] = 0;
-            continue;
+            alive = false;
         }
 
         // ---- block E scan, M:1633-1649 ----
-        if (!iiwarm) {
+        if (alive && !iiwarm) {
             int k0l = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -534,22 +544,47 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             }
         }
 
-        if (a.debug_stop == 1) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+        }   // alive: pass 0
+        if (a.debug_stop == 1) { if (alive && lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
+        if (CPW > 1) {
+            if (lane == 0) s_alive[wv] = alive ? 1 : 0;
+            if (threadIdx.x == 0) s_next = 0;
+            __syncthreads();                                 // S0 images of all CPW columns complete
+        }
         // ============ pass 1: blocks D-J (M:1545-2569), then K, L(snow), rain PSD, M, N (M:2574-2960) ============
         // Blocks K-N are pointwise in k and only consume the tendencies of block J, so they run in the same
         // sweep over the level: the tendencies stay in registers and no input is read twice.
-        double mvdK[NJ];
+        if (CPW == 1 && !alive) return;
+#undef L
+#define L(slot, k) Lp[(slot) * NL + (k)]
+        const int nband = (nz + BL - 1) / BL;
 #pragma unroll 1
-        for (int j = 0; j < NJ; ++j) {
-            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-            put(mvdK, j, 0.);
-            put(pst, j, pick(pst, j) & 31);
-            if (k >= nzu) continue;
-            const int f = pick(pst, j) & 31;
-            const bool L_qc = f & F_QC, L_qi = f & F_QI, L_qr = f & F_QR, L_qs = f & F_QS, L_qg = f & F_QG;
+        for (int it = 0;; ++it) {
+            // one wave pass = one band of every column of the workgroup; lane -> (column cw, level k).
+            // Bands are handed out dynamically (their cost differs by regime), from the middle of the column
+            // outwards: the mixed-phase levels are the expensive ones and should not be left for last.
+            int seq = it;
+            if (CPW > 1) {
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&s_next, 1);
+                seq = __builtin_amdgcn_readfirstlane(t);
+            }
+            if (seq >= nband) break;
+            const int band = CPW > 1 ? (nband - 1) / 2 + ((seq & 1) ? (seq + 1) / 2 : -(seq / 2)) : seq;
+            const int cw = CPW > 1 ? lane / BL : 0;
+            const unsigned k = unsigned(band * BL) + unsigned(lane % BL);
+            // No `continue` in this loop: lanes that skipped ahead to the next iteration on their own would
+            // take the next band without the rest of the wave (the compiler is free to split a loop with several
+            // back edges into nested loops); the wave barrier at the end pins the single join point.
+            if (k < nzu && (CPW == 1 || s_alive[cw])) {
+            double *const Lp = Lsh[cw];
+            const unsigned gk = unsigned(cw) * nzu + k;      // level index within the workgroup's block of columns
+            // block B's flags: pass 0 left the cleaned mixing ratios (0 where q <= R1) in LDS
+            const bool L_qc = L(V_RC, k) > 0., L_qi = L(V_RI, k) > 0., L_qr = L(V_RR, k) > 0., L_qs = L(V_RS, k) > 0.,
+                       L_qg = L(V_RG, k) > 0.;
             CArgs *ka1 = kargs();
-            const double pres = gptr(ka1->p, base)[k], nwfa1 = gptr(ka1->nwfa, base)[k], nifa1 = gptr(ka1->nifa, base)[k];
-            gdouble *grates = RATES ? gptr(ka1->rates, col * int64_t(KIDMP_NRATES_) * nz) : nullptr;
+            const double pres = gptr(ka1->p, base0)[gk], nwfa1 = gptr(ka1->nwfa, base0)[gk], nifa1 = gptr(ka1->nifa, base0)[gk];
+            gdouble *grates = RATES ? gptr(ka1->rates, col0 * int64_t(KIDMP_NRATES_) * nz) + int64_t(cw) * KIDMP_NRATES_ * nz : nullptr;
             const double temp = L(V_TEMP, k), qv_raw = L(V_QV, k), rho = L(V_RHO, k);
             const double qv = fmax(1.E-10, qv_raw);
             const double rc = L_qc ? L(V_RC, k) * rho : R1, ri = L_qi ? L(V_RI, k) * rho : R1,
@@ -960,7 +995,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
 
             // inputs of block J: requested now, consumed after the limiters
             CArgs *kaJ = kargs();
-            const double nc1_raw = gptr(kaJ->nc, base)[k], ni1_raw = gptr(kaJ->ni, base)[k], nr1_raw = gptr(kaJ->nr, base)[k];
+            const double nc1_raw = gptr(kaJ->nc, base0)[gk], ni1_raw = gptr(kaJ->ni, base0)[gk], nr1_raw = gptr(kaJ->nr, base0)[gk];
             const double qc1 = L(V_RC, k), qi1 = L(V_RI, k), qr1 = L(V_RR, k);
 
             // ---- I: conservation limiters, M:2297-2385 ----
@@ -1154,6 +1189,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             const double lvt2 = lvap * lvap * ocp * oRv * otemp * otemp;
 
             int f2 = 0;
+            double mvdK = 0.;
             double rc = R1, nc = 2., ri = R1, ni = R2, rr = R1, nr = R2, rs = R1, rg = R1;
             if ((qc1 + qcten * DT) > R1) { rc = (qc1 + qcten * DT) * rho; nc = Nt_c; f2 |= F_QC; }
             if ((qi1 + qiten * DT) > R1) {
@@ -1169,11 +1205,13 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                 double mvd = (3.0 + mu_r + 0.672) / lr;
                 if (mvd > 2.5E-3)           { mvd = 2.5E-3;      nr = nr_from_mvd(c, rr, mvd); }
                 else if (mvd < D0r * 0.75)  { mvd = D0r * 0.75;  nr = nr_from_mvd(c, rr, mvd); }
-                put(mvdK, j, mvd);
+                mvdK = mvd;
             }
             if ((qs1 + qsten * DT) > R1) { rs = (qs1 + qsten * DT) * rho; f2 |= F_QS; }
             if ((qg1 + qgten * DT) > R1) { rg = (qg1 + qgten * DT) * rho; f2 |= F_QG; }
-            put(pst, j, f | (f2 << 8) | (temp >= 270.65 ? 1 << 16 : 0));     // temp: for k_0 of M:2718-2721
+            // for the second graupel-intercept scan (pass 3, M:2717-2737): rain mvd of block K (0: no rain), with
+            // "temp >= 270.65" (k_0 of M:2718-2721) in the sign bit.  It crosses waves, so it goes through memory.
+            gptr(kargs()->scratch, base0)[gk] = temp >= 270.65 ? -mvdK : mvdK;
 
             // ---- L: snow moments needed later (smoc/smob only), M:2663-2698 ----
             double xDs = 0.;
@@ -1284,9 +1322,9 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
 
             // qv and the (inert) aerosol numbers are final here: blocks O-Q do not touch them
             CArgs *kaN = kargs();
-            gptr(kaN->qv, base)[k] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
-            gptr(kaN->nwfa, base)[k] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (nwfa1 + nwfaten * DT)));   // M:3628
-            gptr(kaN->nifa, base)[k] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (nifa1 + 0. * DT)));       // M:3630
+            gptr(kaN->qv, base0)[gk] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
+            gptr(kaN->nwfa, base0)[gk] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (nwfa1 + nwfaten * DT)));   // M:3628
+            gptr(kaN->nifa, base0)[gk] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (nifa1 + 0. * DT)));       // M:3630
 
             L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
             L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
@@ -1296,9 +1334,15 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             L(V_RR2, k) = rr;      L(V_NR2, k) = nr;      L(V_RS2, k) = rs;  L(V_RG2, k) = rg;
             L(V_XDS, k) = xDs;     L(V_OCP, k) = ocp;     L(V_LVAP, k) = lvap;
             }   // blocks K-N
+            }   // valid (column, level)
+            __builtin_amdgcn_wave_barrier();
         }
 
-        if (a.debug_stop == 3) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+#undef L
+#define L(slot, k) Lw[(slot) * NL + (k)]
+        if (CPW > 1) __syncthreads();                        // S1/S2 images (and the scratch profile) complete
+        if (a.debug_stop == 3) { if (alive && lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
+        if (!alive) return;
         // ============ pass 3: fall speeds, M:3206-3354 ============
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
         double odz[NJ], orho_[NJ], tmp2[NJ];
@@ -1358,9 +1402,15 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             // graupel slope from the second running minimum, M:2717-2737
             {
                 int k0l = 0;
+                double mvdK[NJ];
+                const gdouble *gscr = gptr(kargs()->scratch, base);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    if (pst[j] >> 16) k0l = lane + WAVE * j;
+                for (int j = 0; j < NJ; ++j) {
+                    const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+                    const double sv = k < nzu ? gscr[k] : 0.;
+                    mvdK[j] = fabs(sv);
+                    if (k < nzu && __builtin_signbit(sv)) k0l = int(k);
+                }
                 const int k_0 = wave_max_i(k0l);
                 double n0[NJ];
 #pragma unroll
@@ -1368,7 +1418,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                     n0[j] = __builtin_inf();
                     if (k < nzu)
-                        n0[j] = graupel_N0(int(k) > k_0 && ((pst[j] >> 8) & F_QR) && mvdK[j] > 100.E-6, mvdK[j], L(V_RG2, k));
+                        n0[j] = graupel_N0(int(k) > k_0 && mvdK[j] > 100.E-6, mvdK[j], L(V_RG2, k));
                 }
                 suffix_min<NJ>(n0);
 #pragma unroll
@@ -1506,7 +1556,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             ns[col * 4 + 2] = nstep_s; ns[col * 4 + 3] = nstep_g;
         }
 
-        if (a.debug_stop == 4) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+        if (a.debug_stop == 4) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
         // ============ pass 4: sedimentation sweeps, M:3365-3578 ============
         double ppt_r = 0., ppt_s = 0., ppt_g = 0., ppt_i = 0.;
         {   // rain (never gated by l_sediment), M:3365-3399
@@ -1632,19 +1682,28 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             pp[3] = pp[3] + ppt_i;
         }
 
-        if (a.debug_stop == 5) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); continue; }   // profiling aid only
+        if (a.debug_stop == 5) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
         // ============ pass 5: blocks Q + R, M:3584-3686 ============
-#pragma unroll 1
+        // the column's state is read again (block B's cleaned inputs): all loads of the column in one round trip
+        CArgs *ka = kargs();
+        gdouble *gqc = gptr(ka->qc, base), *gnc = gptr(ka->nc, base), *gqi = gptr(ka->qi, base),
+                *gni = gptr(ka->ni, base), *gqr = gptr(ka->qr, base), *gnr = gptr(ka->nr, base),
+                *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base), *gt = gptr(ka->t, base);
+        double o_qc[NJ], o_nc[NJ], o_qi[NJ], o_ni[NJ], o_qr[NJ], o_nr[NJ], o_qs[NJ], o_qg[NJ], o_t[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+            const unsigned kc = k < nzu ? k : kteu;
+            o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qr[j] = gqr[kc];
+            o_nr[j] = gnr[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc]; o_t[j] = gt[kc];
+        }
+#pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             if (k >= nzu) continue;
-            const int f = pick(pst, j) & 31;
-            CArgs *ka = kargs();
-            gdouble *gqc = gptr(ka->qc, base), *gnc = gptr(ka->nc, base), *gqi = gptr(ka->qi, base),
-                    *gni = gptr(ka->ni, base), *gqr = gptr(ka->qr, base), *gnr = gptr(ka->nr, base),
-                    *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base), *gt = gptr(ka->t, base);
-            const double rqc = gqc[k], rnc = gnc[k], rqi = gqi[k], rni = gni[k], rqr = gqr[k], rnr = gnr[k],
-                         rqs = gqs[k], rqg = gqg[k], t1 = gt[k];       // one batch, cleaned below (block B)
+            const int f = pst[j] & 31;
+            const double rqc = o_qc[j], rnc = o_nc[j], rqi = o_qi[j], rni = o_ni[j], rqr = o_qr[j], rnr = o_nr[j],
+                         rqs = o_qs[j], rqg = o_qg[j], t1 = o_t[j];     // cleaned below (block B)
             const double qc1 = (f & F_QC) ? rqc : 0.0, nc1 = (f & F_QC) ? rnc : 0.0;
             const double qi1 = (f & F_QI) ? rqi : 0.0, ni1 = (f & F_QI) ? rni : 0.0;
             const double qr1 = (f & F_QR) ? rqr : 0.0, nr1 = (f & F_QR) ? rnr : 0.0;
@@ -1729,7 +1788,7 @@ __global__ __launch_bounds__(WPB *WAVE, 2) void thompson_column_step(const StepA
             const double qg = qg1 + qgten * DT;
             gqg[k] = qg <= R1 ? 0.0 : qg;
         }
-    } while (false);
+    }
 }
 
 const char *column_kernel_name() { return "thompson_column_step"; }
@@ -1764,12 +1823,12 @@ hipError_t upload_consts(int slot, const Consts &c)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_consts), &c, sizeof(Consts), size_t(slot) * sizeof(Consts), hipMemcpyHostToDevice);
 }
 
-template <int NJ, int NL>
+template <int NJ, int NL, int CPW>
 static hipError_t launch_nj(const StepArgs &a, bool rates, int grid, hipStream_t s)
 {
-    const int g = (grid + WPB - 1) / WPB;
-    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, true>), dim3(g), dim3(WPB * WAVE), 0, s, a);
-    else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, false>), dim3(g), dim3(WPB * WAVE), 0, s, a);
+    const int g = (grid + CPW - 1) / CPW;
+    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, true>), dim3(g), dim3(CPW * WAVE), 0, s, a);
+    else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, false>), dim3(g), dim3(CPW * WAVE), 0, s, a);
     return hipGetLastError();
 }
 
@@ -1780,12 +1839,19 @@ hipError_t launch_column_step(const StepArgs &a, hipStream_t s)
     if (a.ncol > int64_t(0x7fffffff)) return hipErrorInvalidValue;   // one workgroup per column; 2^31 columns exceed HBM anyway
     const int grid = int(a.ncol);
     const bool rates = a.rates != nullptr;
-    // LDS per column = 21 slots * NL * 8 B; NL = 120 (KiD's nz) gives 8 resident columns per CU
-    if (a.nz <= 64)  return launch_nj<1, 64>(a, rates, grid, s);
-    if (a.nz <= 120) return launch_nj<2, 120>(a, rates, grid, s);
-    if (a.nz <= 128) return launch_nj<2, 128>(a, rates, grid, s);
-    if (a.nz <= 192) return launch_nj<3, 192>(a, rates, grid, s);
-    return launch_nj<4, 256>(a, rates, grid, s);
+    if (!a.scratch) return hipErrorInvalidValue;
+    // LDS per column = 21 slots * NL * 8 B; NL = 120 (KiD's nz) gives 8 resident columns per CU, as two
+    // workgroups of 4.  Taller columns run one column per workgroup (4 images would not leave two workgroups
+    // per CU, or not fit at all).
+    if (a.nz <= 64)  return launch_nj<1, 64, 4>(a, rates, grid, s);
+    if (a.nz <= 120) {
+        static const int cpw = getenv("KIDMP_CPW") ? atoi(getenv("KIDMP_CPW")) : 4;   // tuning aid: 1 = no banding
+        if (cpw == 1) return launch_nj<2, 120, 1>(a, rates, grid, s);
+        return launch_nj<2, 120, 4>(a, rates, grid, s);
+    }
+    if (a.nz <= 128) return launch_nj<2, 128, 1>(a, rates, grid, s);
+    if (a.nz <= 192) return launch_nj<3, 192, 1>(a, rates, grid, s);
+    return launch_nj<4, 256, 1>(a, rates, grid, s);
 }
 
 }  // namespace kidmp
