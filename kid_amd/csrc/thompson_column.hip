@@ -311,6 +311,8 @@ __device__ inline double nr_from_mvd(const Consts &c, double rr, double mvd)
 enum Slot {
     // S0 (written in pass 0, read in pass 1)
     V_TEMP = 0, V_QV, V_RHO, V_RC, V_RI, V_RR, V_RS, V_RG, V_NI, V_NR, V_QVSI, V_SSATW, V_SSATI, V_DIFFU, V_N0X,
+    //    raw inputs that pass 1 needs as well: fetched once, with the rest of the column, in pass 0
+    V_PRES, V_NWFA, V_NIFA, V_NCRAW, V_NIRAW, V_NRRAW,
     // S1 (written at the end of pass 1)
     V_TTEN = 0, V_QVTEN, V_QCTEN, V_NCTEN, V_QITEN, V_NITEN, V_QRTEN, V_NRTEN, V_QSTEN, V_QGTEN,
     V_PRRGML, V_BOOST,
@@ -409,18 +411,21 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
         if (alive) {
         // all first-touch HBM loads of the column are issued together (one round trip):
         double i_t[NJ], i_qv[NJ], i_p[NJ], i_qc[NJ], i_qi[NJ], i_qr[NJ], i_qs[NJ], i_qg[NJ], i_ni[NJ], i_nr[NJ];
+        double i_nc[NJ], i_nwfa[NJ], i_nifa[NJ];
         {
         CArgs *ka = kargs();
         const gdouble *gt = gptr(ka->t, base), *gqv = gptr(ka->qv, base), *gp = gptr(ka->p, base),
                       *gqc = gptr(ka->qc, base), *gqi = gptr(ka->qi, base), *gqr = gptr(ka->qr, base),
                       *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base), *gni = gptr(ka->ni, base),
-                      *gnr = gptr(ka->nr, base);
+                      *gnr = gptr(ka->nr, base), *gnc = gptr(ka->nc, base), *gnwfa = gptr(ka->nwfa, base),
+                      *gnifa = gptr(ka->nifa, base);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             const unsigned kc = k < nzu ? k : kteu;                 // clamped: loads stay unconditional
             i_t[j] = gt[kc];   i_qv[j] = gqv[kc]; i_p[j] = gp[kc];   i_qc[j] = gqc[kc]; i_qi[j] = gqi[kc];
             i_qr[j] = gqr[kc]; i_qs[j] = gqs[kc]; i_qg[j] = gqg[kc]; i_ni[j] = gni[kc]; i_nr[j] = gnr[kc];
+            i_nc[j] = gnc[kc]; i_nwfa[j] = gnwfa[kc]; i_nifa[j] = gnifa[kc];
         }
         }
 #pragma unroll
@@ -495,6 +500,8 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             L(V_RS, k) = (f & F_QS) ? qs1 : 0.;  L(V_RG, k) = (f & F_QG) ? qg1 : 0.;
             L(V_NI, k) = ni;      L(V_NR, k) = nr;    L(V_QVSI, k) = qvsi;
             L(V_SSATW, k) = ssatw; L(V_SSATI, k) = ssati;
+            L(V_PRES, k) = pres;  L(V_NWFA, k) = i_nwfa[j]; L(V_NIFA, k) = i_nifa[j];
+            L(V_NCRAW, k) = i_nc[j]; L(V_NIRAW, k) = i_ni[j]; L(V_NRRAW, k) = i_nr[j];
             if (!iiwarm) L(V_DIFFU, k) = diffusivity(temp, pres);    // M:1522 (only the frozen-species block reads it)
         }
 
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             const bool L_qc = L(V_RC, k) > 0., L_qi = L(V_RI, k) > 0., L_qr = L(V_RR, k) > 0., L_qs = L(V_RS, k) > 0.,
                        L_qg = L(V_RG, k) > 0.;
             CArgs *ka1 = kargs();
-            const double pres = gptr(ka1->p, base0)[gk], nwfa1 = gptr(ka1->nwfa, base0)[gk], nifa1 = gptr(ka1->nifa, base0)[gk];
+            const double pres = L(V_PRES, k);
             gdouble *grates = RATES ? gptr(ka1->rates, col0 * int64_t(KIDMP_NRATES_) * nz) + int64_t(cw) * KIDMP_NRATES_ * nz : nullptr;
             const double temp = L(V_TEMP, k), qv_raw = L(V_QV, k), rho = L(V_RHO, k);
             const double qv = fmax(1.E-10, qv_raw);
@@ -994,8 +1001,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             }
 
             // inputs of block J: requested now, consumed after the limiters
-            CArgs *kaJ = kargs();
-            const double nc1_raw = gptr(kaJ->nc, base0)[gk], ni1_raw = gptr(kaJ->ni, base0)[gk], nr1_raw = gptr(kaJ->nr, base0)[gk];
+            const double nc1_raw = L(V_NCRAW, k), ni1_raw = L(V_NIRAW, k), nr1_raw = L(V_NRRAW, k);
             const double qc1 = L(V_RC, k), qi1 = L(V_RI, k), qr1 = L(V_RR, k);
 
             // ---- I: conservation limiters, M:2297-2385 ----
@@ -1322,6 +1328,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 
             // qv and the (inert) aerosol numbers are final here: blocks O-Q do not touch them
             CArgs *kaN = kargs();
+            const double nwfa1 = L(V_NWFA, k), nifa1 = L(V_NIFA, k);
             gptr(kaN->qv, base0)[gk] = fmax(1.E-10, qv1 + qvten * DT);                                         // M:3625
             gptr(kaN->nwfa, base0)[gk] = fmax(11.1E6 / rho, fmin(9999.E6 / rho, (nwfa1 + nwfaten * DT)));   // M:3628
             gptr(kaN->nifa, base0)[gk] = fmax(naIN1 * 0.01, fmin(9999.E6 / rho, (nifa1 + 0. * DT)));       // M:3630
@@ -1343,6 +1350,24 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
         if (CPW > 1) __syncthreads();                        // S1/S2 images (and the scratch profile) complete
         if (a.debug_stop == 3) { if (alive && lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
         if (!alive) return;
+        // Everything the remaining passes read from memory is requested here, in one round trip that the fall-speed
+        // and sedimentation passes hide: dz and the block-K rain mvd (pass 3), and the column's state as block B
+        // left it (pass 5 adds the tendencies to it).
+        CArgs *ka = kargs();
+        gdouble *gqc = gptr(ka->qc, base), *gnc = gptr(ka->nc, base), *gqi = gptr(ka->qi, base),
+                *gni = gptr(ka->ni, base), *gqr = gptr(ka->qr, base), *gnr = gptr(ka->nr, base),
+                *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base), *gt = gptr(ka->t, base);
+        const gdouble *gdz = gptr(ka->dz, base), *gscr = gptr(ka->scratch, base);
+        double o_qc[NJ], o_nc[NJ], o_qi[NJ], o_ni[NJ], o_qr[NJ], o_nr[NJ], o_qs[NJ], o_qg[NJ], o_t[NJ];
+        double pf_dz[NJ], pf_scr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
+            const unsigned kc = k < nzu ? k : kteu;
+            pf_dz[j] = gdz[kc]; pf_scr[j] = gscr[kc];
+            o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qr[j] = gqr[kc];
+            o_nr[j] = gnr[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc]; o_t[j] = gt[kc];
+        }
         // ============ pass 3: fall speeds, M:3206-3354 ============
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
         double odz[NJ], orho_[NJ], tmp2[NJ];
@@ -1358,7 +1383,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             odz[j] = 0.; orho_[j] = 0.; tmp2[j] = 0.; ok[j] = 0; dzv[j] = 1.; rhofv[j] = 0.;
             if (k >= nzu) continue;
             const double rho = L(V_RHO2, k);
-            dzv[j] = gptr(kargs()->dz, base)[k];
+            dzv[j] = pf_dz[j];
             odz[j] = 1. / dzv[j];
             orho_[j] = 1. / rho;
             tmp2[j] = L(V_TEMP2, k);
@@ -1403,11 +1428,10 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             {
                 int k0l = 0;
                 double mvdK[NJ];
-                const gdouble *gscr = gptr(kargs()->scratch, base);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                    const double sv = k < nzu ? gscr[k] : 0.;
+                    const double sv = k < nzu ? pf_scr[j] : 0.;
                     mvdK[j] = fabs(sv);
                     if (k < nzu && __builtin_signbit(sv)) k0l = int(k);
                 }
@@ -1683,20 +1707,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
         }
 
         if (a.debug_stop == 5) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
-        // ============ pass 5: blocks Q + R, M:3584-3686 ============
-        // the column's state is read again (block B's cleaned inputs): all loads of the column in one round trip
-        CArgs *ka = kargs();
-        gdouble *gqc = gptr(ka->qc, base), *gnc = gptr(ka->nc, base), *gqi = gptr(ka->qi, base),
-                *gni = gptr(ka->ni, base), *gqr = gptr(ka->qr, base), *gnr = gptr(ka->nr, base),
-                *gqs = gptr(ka->qs, base), *gqg = gptr(ka->qg, base), *gt = gptr(ka->t, base);
-        double o_qc[NJ], o_nc[NJ], o_qi[NJ], o_ni[NJ], o_qr[NJ], o_nr[NJ], o_qs[NJ], o_qg[NJ], o_t[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-            const unsigned kc = k < nzu ? k : kteu;
-            o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qr[j] = gqr[kc];
-            o_nr[j] = gnr[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc]; o_t[j] = gt[kc];
-        }
+        // ============ pass 5: blocks Q + R, M:3584-3686 (inputs requested before pass 3) ============
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
