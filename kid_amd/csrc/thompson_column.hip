@@ -1600,12 +1600,9 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                    if (k == kteu) {
-                        qt[j] = qt[j] - sr[j] * odz[j] * onstep_r * orho_[j];
-                        nt[j] = nt[j] - sn[j] * odz[j] * onstep_r * orho_[j];
-                        r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onstep_r);
-                        n[j] = fmax(R2, n[j] - sn[j] * odz[j] * DT * onstep_r);
-                    } else if (int(k) <= ksed_r) {
+                    // the top level (M:3370-3377) is the general update with nothing falling in: ur = un = 0 there
+                    // (the slot above holds r = 0), and q - x == q + (0 - x) bit for bit
+                    if (k == kteu || int(k) <= ksed_r) {
                         qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_r * orho_[j];
                         nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_r * orho_[j];
                         r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_r);
@@ -1638,12 +1635,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                        if (k == kteu) {
-                            qt[j] = qt[j] - sr[j] * odz[j] * onstep_i * orho_[j];
-                            nt[j] = nt[j] - sn[j] * odz[j] * onstep_i * orho_[j];
-                            r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onstep_i);
-                            n[j] = fmax(R2, n[j] - sn[j] * odz[j] * DT * onstep_i);
-                        } else if (int(k) <= ksed_i) {
+                        if (k == kteu || int(k) <= ksed_i) {     // top level: as for rain
                             qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_i * orho_[j];
                             nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_i * orho_[j];
                             r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_i);
@@ -1680,10 +1672,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                        if (k == kteu) {
-                            qt[j] = qt[j] - sr[j] * odz[j] * onst * orho_[j];
-                            r[j] = fmax(R1, r[j] - sr[j] * odz[j] * DT * onst);
-                        } else if (int(k) <= ksed) {
+                        if (k == kteu || int(k) <= ksed) {
                             qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onst * orho_[j];
                             r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onst);
                         }
