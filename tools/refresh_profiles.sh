@@ -1,0 +1,23 @@
+#!/bin/bash
+# Regenerates everything under profiles/ for one round tag (run on the GPU box; results land in gpurun_out/):
+#   tools/refresh_profiles.sh r01
+set -e
+export TMPDIR=/tmp
+tag=${1:-r01}
+out=gpurun_out/profiles_$tag
+mkdir -p $out
+for w in config2 config3 config5; do
+  bash tools/pmc_profile.sh $w ${tag}_$w > /dev/null
+  cp gpurun_out/pmc_${tag}_$w.json $out/${tag}_pmc_$w.json
+  echo "pmc $w done"
+done
+# the bench reads profiles/<tag>_pmc_<workload>.json for the measured HBM traffic
+mkdir -p profiles && cp $out/${tag}_pmc_*.json profiles/
+for w in config2 config3 config5; do
+  python bench.py --workload $w > $out/${tag}_bench_$w.json
+  echo "bench $w: $(cut -c1-200 $out/${tag}_bench_$w.json)"
+done
+rm -rf gpurun_out/prof_$tag
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
+cp $(ls -t gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1) $out/${tag}_config2_kernel_stats.csv
+cat $out/${tag}_config2_kernel_stats.csv | head -5
