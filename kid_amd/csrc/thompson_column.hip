@@ -375,6 +375,9 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
     __shared__ double Lsh[CPW][NSLOT * NL];          // one [NSLOT][NL] image per column
     __shared__ int s_alive[CPW];                     // column takes part in pass 1 (exists and has microphysics)
     __shared__ int s_next;                           // pass 1: next band to hand out
+    // the cloud-droplet gamma constants indexed by nu_c (1..15, per level): LDS copies, a per-lane index into the
+    // constant address space would be a vector load with a full memory round trip at each use
+    __shared__ double s_cc[6][16];                   // rows: ccg(1,:), ccg(2,:), ocg1, ocg2, cce(2,:), dcg_fac
     const int wv = CPW > 1 ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE) : 0;
     double *const Lw = Lsh[wv];
 #define L(slot, k) Lw[(slot) * NL + (k)]
@@ -389,6 +392,11 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
     const double DT = a.dt;
     const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
     const double Nt_c = c.Nt_c;
+    for (int t = threadIdx.x; t < 96; t += CPW * WAVE) {  // read after the first barrier (CPW > 1) / by the same wave
+        const int row = t >> 4, i = t & 15, ii = i < 15 ? i : 14;
+        s_cc[row][i] = row == 0 ? c.ccg[0][ii] : row == 1 ? c.ccg[1][ii] : row == 2 ? c.ocg1[ii]
+                     : row == 3 ? c.ocg2[ii] : row == 4 ? c.cce[1][ii] : c.dcg_fac[ii];
+    }
 
     // One column per wave, one launch covers all columns (grid = ncol / CPW workgroups).  Deliberately not a
     // grid-stride loop: a loop invites the compiler to hoist every column-invariant scalar (dt-derived values,
@@ -686,11 +694,11 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
                 nu_c = int(lround(1000.E6 / nc)) + 2;
                 nu_c = nu_c < 15 ? nu_c : 15;
                 xDc = fmax(D0c * 1.E6, root3(rc / (am_r * nc)) * 1.E6);
-                lamc = root3(nc * am_r * c.ccg[1][nu_c - 1] * c.ocg1[nu_c - 1] / rc);
+                lamc = root3(nc * am_r * s_cc[1][nu_c - 1] * s_cc[2][nu_c - 1] / rc);
                 mvd_c = (3.0 + nu_c + 0.672) / lamc;
             }
             if (rc > 0.01e-3) {                              // Berry & Reinhardt, M:1698-1712
-                const double Dc_g = (c.dcg_fac[nu_c - 1] / lamc) * 1.E6;
+                const double Dc_g = (s_cc[5][nu_c - 1] / lamc) * 1.E6;
                 const double Dc_b = root6(xDc * xDc * xDc * Dc_g * Dc_g * Dc_g - xDc * xDc * xDc * xDc * xDc * xDc);
                 const double zq = 6.25E-6 * xDc * Dc_b * Dc_b * Dc_b - 0.4;
                 const double zeta1 = 0.5 * (zq + fabs(zq));
@@ -1070,15 +1078,15 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
                 if (xrc > R1) {
                     int nu = int(lround(1000.E6 / xnc)) + 2;
                     nu = nu < 15 ? nu : 15;
-                    double lc = root3(xnc * am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] / rc);
+                    double lc = root3(xnc * am_r * s_cc[1][nu - 1] * s_cc[2][nu - 1] / rc);
                     const double xD = (bm_r + nu + 1.) / lc;
                     if (xD < D0c) {
-                        lc = c.cce[1][nu - 1] / D0c;
-                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * cube(lc);
+                        lc = s_cc[4][nu - 1] / D0c;
+                        xnc = s_cc[0][nu - 1] * s_cc[3][nu - 1] * xrc / am_r * cube(lc);
                         ncten = (xnc - nc1 * rho) * odts * orho;
                     } else if (xD > D0r * 2.) {
-                        lc = c.cce[1][nu - 1] / (D0r * 2.);
-                        xnc = c.ccg[0][nu - 1] * c.ocg2[nu - 1] * xrc / am_r * cube(lc);
+                        lc = s_cc[4][nu - 1] / (D0r * 2.);
+                        xnc = s_cc[0][nu - 1] * s_cc[3][nu - 1] * xrc / am_r * cube(lc);
                         ncten = (xnc - nc1 * rho) * odts * orho;
                     }
                 } else {
@@ -1744,11 +1752,11 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             } else {
                 int nu = int(lround(1000.E6 / (ncn * rho))) + 2;
                 nu = nu < 15 ? nu : 15;
-                double lc = root3(am_r * c.ccg[1][nu - 1] * c.ocg1[nu - 1] * ncn / qc);
+                double lc = root3(am_r * s_cc[1][nu - 1] * s_cc[2][nu - 1] * ncn / qc);
                 const double xD = (bm_r + nu + 1.) / lc;
-                if (xD < D0c)            lc = c.cce[1][nu - 1] / D0c;
-                else if (xD > D0r * 2.)  lc = c.cce[1][nu - 1] / (D0r * 2.);
-                ncn = fmin(c.ccg[0][nu - 1] * c.ocg2[nu - 1] * qc / am_r * cube(lc), Nt_c_max / rho);
+                if (xD < D0c)            lc = s_cc[4][nu - 1] / D0c;
+                else if (xD > D0r * 2.)  lc = s_cc[4][nu - 1] / (D0r * 2.);
+                ncn = fmin(s_cc[0][nu - 1] * s_cc[3][nu - 1] * qc / am_r * cube(lc), Nt_c_max / rho);
             }
             gqc[k] = qc;
             gnc[k] = ncn;
