@@ -93,6 +93,11 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
                             double *ppt, double *rates, int32_t *nstep,
                             void *stream);
 
+/* Sizes the context's internal work buffer for batches of up to ncol columns of nz levels.  Optional:
+ * kidmp_batch_step_device grows it on demand, but that allocates (and synchronises the device); after
+ * kidmp_reserve, calls with ncol*nz no larger never allocate, so they can be captured into a hipGraph. */
+int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz);
+
 /* Non-aerosol defaults for nc1d/nwfa1d/nifa1d, which the KiD wrapper leaves
  * unset (W:36): nc=Nt_c/rho, nwfa=11.1e6/rho, nifa=naIN1*0.01/rho with
  * rho=0.622p/(R T (qv+0.622)) (M:958-964).  Device pointers, [ncol*nz]. */

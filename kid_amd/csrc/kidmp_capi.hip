@@ -170,6 +170,19 @@ __global__ void k_math_probe(int fn, int64_t n, const double *x, const double *y
     out[i] = r;
 }
 
+// the [ncol][nz] work profile of the column kernel; grows, never shrinks
+int ensure_scratch(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
+{
+    const size_t need = size_t(ncol) * size_t(nz);
+    if (need <= ctx->scratch_elems) return KIDMP_OK;
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);  // hipFree waits for launches still using the old buffer
+    ctx->d_scratch = nullptr;
+    ctx->scratch_elems = 0;
+    HIPTRY(ctx, hipMalloc((void **)&ctx->d_scratch, need * sizeof(double)));
+    ctx->scratch_elems = need;
+    return KIDMP_OK;
+}
+
 int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const void *const *ptrs, int nptr)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
@@ -277,17 +290,18 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     a.ncol = ncol; a.nz = nz; a.dt = dt;
     a.debug_stop = ctx->debug_stop;
     if (ncol == 0) return KIDMP_OK;
-    const size_t need = size_t(ncol) * size_t(nz);
-    if (need > ctx->scratch_elems) {                     // hipFree waits for launches still using the old buffer
-        if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
-        ctx->d_scratch = nullptr;
-        ctx->scratch_elems = 0;
-        HIPTRY(ctx, hipMalloc((void **)&ctx->d_scratch, need * sizeof(double)));
-        ctx->scratch_elems = need;
-    }
+    if (int rc = ensure_scratch(ctx, ncol, nz)) return rc;
     a.scratch = ctx->d_scratch;
     HIPTRY(ctx, launch_column_step(a, (hipStream_t)stream));
     return KIDMP_OK;
+}
+
+int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return fail(ctx, KIDMP_EINVAL, "kidmp_reserve: bad argument");
+    HIPTRY(ctx, hipSetDevice(ctx->cfg.device));
+    return ensure_scratch(ctx, ncol, nz);
 }
 
 int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,

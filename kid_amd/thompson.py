@@ -76,6 +76,8 @@ def load_library():
     L.kidmp_default_aerosols_device.argtypes = [_vp, C.c_int64] + [_vp] * 6 + [_vp]
     L.kidmp_reduce_ppt_device.restype = C.c_int
     L.kidmp_reduce_ppt_device.argtypes = [_vp, C.c_int64, _vp, _vp, _vp]
+    L.kidmp_reserve.restype = C.c_int
+    L.kidmp_reserve.argtypes = [_vp, C.c_int64, C.c_int32]
     L.kidmp_math_probe.restype = C.c_int
     L.kidmp_math_probe.argtypes = [_vp, C.c_int32, C.c_int64, _dp, _dp, _dp]
     L.kidmp_get_table.restype = C.c_int64
@@ -201,6 +203,10 @@ class ThompsonMP:
             self._h, qv.numel(), qv.data_ptr(), t.data_ptr(), p.data_ptr(), nc.data_ptr(), nwfa.data_ptr(),
             nifa.data_ptr(), s))
         return nc, nwfa, nifa
+
+    def reserve(self, ncol, nz):
+        """Pre-size the context's work buffer: later batch_step calls of that size never allocate (graph capture)."""
+        self._check(load_library().kidmp_reserve(self._h, ncol, nz))
 
     def reduce_ppt(self, ppt, stream=None):
         """Domain sums of the surface precipitation on the device (W:248-275 analogue)."""
