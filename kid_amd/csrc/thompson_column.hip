@@ -447,11 +447,10 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             const double rho = 0.622 * pres / (Rgas * temp * (qv + 0.622));
             const double qc1 = i_qc[j], qi1 = i_qi[j], qr1 = i_qr[j], qs1 = i_qs[j], qg1 = i_qg[j];
             int f = 0;
-            double rc = R1, ri = R1, ni = R2, rr = R1, nr = R2, rs = R1, rg = R1;
+            double ri = R1, ni = R2, rr = R1, nr = R2, rg = R1;    // rc, rs: only their flags are needed here
 
             if (qc1 > R1) {                                  // M:1395-1418 (nc forced to Nt_c, M:1410)
                 f |= F_QC;
-                rc = qc1 * rho;
             }
             if (qi1 > R1) {                                  // M:1420-1445
                 f |= F_QI;
@@ -487,7 +486,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
                 }
                 mvdB[j] = mvd;
             }
-            if (qs1 > R1) { f |= F_QS; rs = qs1 * rho; }     // M:1475-1483
+            if (qs1 > R1) f |= F_QS;                         // M:1475-1483
             if (qg1 > R1) { f |= F_QG; rg = qg1 * rho; }     // M:1484-1492
             rgB[j] = rg;
 

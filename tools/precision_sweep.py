@@ -60,6 +60,15 @@ def main():
     st = getattr(cases, args.workload)(args.ncol)
     m = ThompsonMP(iiwarm=False)
     cps = sorted({1, 10, args.steps})
+    # CFL substep counts of the first three steps (rain, ice, snow, graupel): the workload is defined by them
+    dev = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+    ppt0 = torch.zeros(args.ncol, 4, dtype=torch.float64, device="cuda")
+    nst = torch.zeros(args.ncol, 4, dtype=torch.int32, device="cuda")
+    for n in (1, 2, 3):
+        m.batch_step(dev, 10.0, ppt0, nstep=nst)
+        h = nst.cpu().numpy()
+        print(json.dumps({"nstep_histogram_step": n, **{name: {int(v): int(c) for v, c in zip(*np.unique(h[:, i], return_counts=True))}
+                                                         for i, name in enumerate(("rain", "ice", "snow", "graupel"))}}))
     ref = run(m, st, "f64", args.steps, cps)
     rows = []
     for mode in ("f32", "bf16x2"):
