@@ -286,7 +286,7 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     a.qv = qv; a.qc = qc; a.qi = qi; a.qr = qr; a.qs = qs; a.qg = qg; a.ni = ni; a.nr = nr;
     a.nc = nc; a.nwfa = nwfa; a.nifa = nifa; a.t = t; a.p = p; a.dz = dz;
     a.ppt = ppt; a.rates = rates; a.nstep = nstep;
-    a.cslot = ctx->cslot; a.tables = ctx->tables;
+    a.cslot = ctx->cslot; a.tables = ctx->tables; a.iiwarm = ctx->cfg.iiwarm != 0;
     a.ncol = ncol; a.nz = nz; a.dt = dt;
     a.debug_stop = ctx->debug_stop;
     if (ncol == 0) return KIDMP_OK;

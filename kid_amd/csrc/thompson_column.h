@@ -19,6 +19,7 @@ struct StepArgs {
     int32_t *nstep;       // nullptr or [ncol][4] rain, ice, snow, graupel
     double *scratch;      // [ncol][nz] work profile owned by the context (block-K rain mvd, pass 1 -> pass 3)
     int32_t cslot;        // slot of this context's Consts in constant memory (upload_consts)
+    int32_t iiwarm;       // the context's iiwarm switch: selects the warm-rain instantiation of the kernel
     Tables tables;
     int64_t ncol;
     int32_t nz;

@@ -368,7 +368,9 @@ __device__ inline CArgs *kargs()
 // and one wave pass handles the same band of all CPW columns.  Lanes of a wave then sit at the same altitude,
 // i.e. in the same microphysical regime (warm rain / melting layer / mixed phase / ice), so far fewer lanes idle
 // in the regime-specific branches than when a wave spans 64 consecutive levels of one column.
-template <int NJ, int NL, int CPW, bool RATES>
+// WARM = the context was initialised with iiwarm (namelists, M:22): the frozen-species blocks are compiled out,
+// so the warm-rain kernel carries neither their code nor their registers.
+template <int NJ, int NL, int CPW, bool RATES, bool WARM>
 __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepArgs a)
 {
     constexpr int BL = WAVE / CPW;                   // levels per band
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
     __builtin_assume(nz >= 2 && nz <= 4 * WAVE);          // checked by launch_column_step
     const int kte = nz - 1;
     const unsigned nzu = unsigned(nz), kteu = unsigned(kte);
-    const bool iiwarm = c.iiwarm != 0;
+    constexpr bool iiwarm = WARM;
     const double DT = a.dt;
     const double odt = 1. / DT, odts = 1. / DT;               // M:1277-1279 (dtsave = dt)
     const double Nt_c = c.Nt_c;
@@ -1834,8 +1836,14 @@ template <int NJ, int NL, int CPW>
 static hipError_t launch_nj(const StepArgs &a, bool rates, int grid, hipStream_t s)
 {
     const int g = (grid + CPW - 1) / CPW;
-    if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, true>), dim3(g), dim3(CPW * WAVE), 0, s, a);
-    else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, false>), dim3(g), dim3(CPW * WAVE), 0, s, a);
+    const dim3 gd(g), bd(CPW * WAVE);
+    if (a.iiwarm) {
+        if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, true, true>), gd, bd, 0, s, a);
+        else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, false, true>), gd, bd, 0, s, a);
+    } else {
+        if (rates) hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, true, false>), gd, bd, 0, s, a);
+        else       hipLaunchKernelGGL((thompson_column_step<NJ, NL, CPW, false, false>), gd, bd, 0, s, a);
+    }
     return hipGetLastError();
 }
 
