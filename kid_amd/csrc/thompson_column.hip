@@ -324,6 +324,19 @@ enum Slot {
 
 enum Flag { F_QC = 1, F_QI = 2, F_QR = 4, F_QS = 8, F_QG = 16 };
 
+// Warm-rain instantiation: the frozen species never leave block B / block R, so their slots (and the ones only
+// the frozen-species blocks read) are not staged at all and the rest is packed into 13 physical slots:
+// 12 480 B per column, 3 workgroups per CU instead of 2.  Indexed by the enumerator's VALUE; -1 = not staged.
+// S0: TEMP QV RHO RC RR NR SSATW PRES NWFA NIFA NCRAW NRRAW;  S1/S2: the tendencies, RHO2, RR2, NR2.
+constexpr int NSLOT_W = 13;
+constexpr int WMAP[NSLOT] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -1, 4, -1, 10, -1, 6, 11, 12, 7, -1, 8};
+template <bool WARM, int S>
+__device__ constexpr int slot_of()
+{
+    static_assert(!WARM || WMAP[S] >= 0, "this slot is not staged in the warm-rain layout");
+    return WARM ? WMAP[S] : S;
+}
+
 }  // namespace
 
 // The ~3 KB of scalar constants live in the constant address space, one slot per
@@ -371,10 +384,10 @@ __device__ inline CArgs *kargs()
 // WARM = the context was initialised with iiwarm (namelists, M:22): the frozen-species blocks are compiled out,
 // so the warm-rain kernel carries neither their code nor their registers.
 template <int NJ, int NL, int CPW, bool RATES, bool WARM>
-__global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepArgs a)
+__global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(const StepArgs a)
 {
     constexpr int BL = WAVE / CPW;                   // levels per band
-    __shared__ double Lsh[CPW][NSLOT * NL];          // one [NSLOT][NL] image per column
+    __shared__ double Lsh[CPW][(WARM ? NSLOT_W : NSLOT) * NL];   // one [slot][NL] image per column
     __shared__ int s_alive[CPW];                     // column takes part in pass 1 (exists and has microphysics)
     __shared__ int s_next;                           // pass 1: next band to hand out
     // the cloud-droplet gamma constants indexed by nu_c (1..15, per level): LDS copies, a per-lane index into the
@@ -382,7 +395,8 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
     __shared__ double s_cc[6][16];                   // rows: ccg(1,:), ccg(2,:), ocg1, ocg2, cce(2,:), dcg_fac
     const int wv = CPW > 1 ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) / WAVE) : 0;
     double *const Lw = Lsh[wv];
-#define L(slot, k) Lw[(slot) * NL + (k)]
+#define L(slot, k) Lw[slot_of<WARM, slot>() * NL + (k)]
+#define LR(slot, k) Lw[(slot) * NL + (k)]            // physical slot number (run-time slots of the frozen-species code)
 
     const Consts &c = g_consts[a.cslot];
     const int lane = lane_id();
@@ -505,13 +519,15 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             L(V_TEMP, k) = temp;  L(V_QV, k) = i_qv[j];   L(V_RHO, k) = rho;     // qv raw: block K needs qv1d itself
             // the cleaned mixing ratios (block B zeroes q <= R1, M:1412...) go to LDS; pass 1 rebuilds
             // rc..rg = q*rho from them with the same product, and block J reads them directly
-            L(V_RC, k) = (f & F_QC) ? qc1 : 0.;  L(V_RI, k) = (f & F_QI) ? qi1 : 0.;  L(V_RR, k) = (f & F_QR) ? qr1 : 0.;
-            L(V_RS, k) = (f & F_QS) ? qs1 : 0.;  L(V_RG, k) = (f & F_QG) ? qg1 : 0.;
-            L(V_NI, k) = ni;      L(V_NR, k) = nr;    L(V_QVSI, k) = qvsi;
-            L(V_SSATW, k) = ssatw; L(V_SSATI, k) = ssati;
+            L(V_RC, k) = (f & F_QC) ? qc1 : 0.;  L(V_RR, k) = (f & F_QR) ? qr1 : 0.;
+            L(V_NR, k) = nr;      L(V_SSATW, k) = ssatw;
             L(V_PRES, k) = pres;  L(V_NWFA, k) = i_nwfa[j]; L(V_NIFA, k) = i_nifa[j];
-            L(V_NCRAW, k) = i_nc[j]; L(V_NIRAW, k) = i_ni[j]; L(V_NRRAW, k) = i_nr[j];
-            if (!iiwarm) L(V_DIFFU, k) = diffusivity(temp, pres);    // M:1522 (only the frozen-species block reads it)
+            L(V_NCRAW, k) = i_nc[j]; L(V_NRRAW, k) = i_nr[j];
+            if constexpr (!iiwarm) {
+                L(V_RI, k) = (f & F_QI) ? qi1 : 0.;  L(V_RS, k) = (f & F_QS) ? qs1 : 0.;  L(V_RG, k) = (f & F_QG) ? qg1 : 0.;
+                L(V_NI, k) = ni;      L(V_QVSI, k) = qvsi;  L(V_SSATI, k) = ssati;  L(V_NIRAW, k) = i_ni[j];
+                L(V_DIFFU, k) = diffusivity(temp, pres);     // M:1522 (only the frozen-species block reads it)
+            }
         }
 
         // ---- no_micro early return, M:1540.  Block B has already zeroed the
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
         }
 
         // ---- block E scan, M:1633-1649 ----
-        if (alive && !iiwarm) {
+        if constexpr (!iiwarm) if (alive) {
             int k0l = 0;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
         }
 
         }   // alive: pass 0
-        if (a.debug_stop == 1) { if (alive && lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
+        if (a.debug_stop == 1) { if (alive && lane == 0) kargs()->ppt[col * 4] += LR(0, 0) + LR(12, 1); return; }   // profiling aid only
         if (CPW > 1) {
             if (lane == 0) s_alive[wv] = alive ? 1 : 0;
             if (threadIdx.x == 0) s_next = 0;
@@ -572,7 +588,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
         // sweep over the level: the tendencies stay in registers and no input is read twice.
         if (CPW == 1 && !alive) return;
 #undef L
-#define L(slot, k) Lp[(slot) * NL + (k)]
+#define L(slot, k) Lp[slot_of<WARM, slot>() * NL + (k)]
         const int nband = (nz + BL - 1) / BL;
 #pragma unroll 1
         for (int it = 0;; ++it) {
@@ -596,20 +612,28 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             double *const Lp = Lsh[cw];
             const unsigned gk = unsigned(cw) * nzu + k;      // level index within the workgroup's block of columns
             // block B's flags: pass 0 left the cleaned mixing ratios (0 where q <= R1) in LDS
-            const bool L_qc = L(V_RC, k) > 0., L_qi = L(V_RI, k) > 0., L_qr = L(V_RR, k) > 0., L_qs = L(V_RS, k) > 0.,
-                       L_qg = L(V_RG, k) > 0.;
             CArgs *ka1 = kargs();
+            // cleaned frozen-species inputs: from the LDS image, or (warm layout: not staged) again from memory
+            double qi1c, qs1c, qg1c, ni_b = R2, ni1_raw, qvsi = 0., ssati = 0., diffu = 0.;
+            if constexpr (iiwarm) {
+                const double rqi = gptr(ka1->qi, base0)[gk], rqs = gptr(ka1->qs, base0)[gk], rqg = gptr(ka1->qg, base0)[gk];
+                ni1_raw = gptr(ka1->ni, base0)[gk];
+                qi1c = rqi > R1 ? rqi : 0.;  qs1c = rqs > R1 ? rqs : 0.;  qg1c = rqg > R1 ? rqg : 0.;
+            } else {
+                qi1c = L(V_RI, k);  qs1c = L(V_RS, k);  qg1c = L(V_RG, k);
+                ni_b = L(V_NI, k);  ni1_raw = L(V_NIRAW, k);
+                qvsi = L(V_QVSI, k);  ssati = L(V_SSATI, k);  diffu = L(V_DIFFU, k);
+            }
+            const bool L_qc = L(V_RC, k) > 0., L_qi = qi1c > 0., L_qr = L(V_RR, k) > 0., L_qs = qs1c > 0., L_qg = qg1c > 0.;
             const double pres = L(V_PRES, k);
             gdouble *grates = RATES ? gptr(ka1->rates, col0 * int64_t(KIDMP_NRATES_) * nz) + int64_t(cw) * KIDMP_NRATES_ * nz : nullptr;
             const double temp = L(V_TEMP, k), qv_raw = L(V_QV, k), rho = L(V_RHO, k);
             const double qv = fmax(1.E-10, qv_raw);
-            const double rc = L_qc ? L(V_RC, k) * rho : R1, ri = L_qi ? L(V_RI, k) * rho : R1,
+            const double rc = L_qc ? L(V_RC, k) * rho : R1, ri = L_qi ? qi1c * rho : R1,
                          rr = L_qr ? L(V_RR, k) * rho : R1;
-            const double qs1c = L(V_RS, k), qg1c = L(V_RG, k);
             const double rs = L_qs ? qs1c * rho : R1, rg = L_qg ? qg1c * rho : R1;
-            const double ni = L(V_NI, k), nr = L(V_NR, k);
-            const double qvsi = L(V_QVSI, k), ssatw = L(V_SSATW, k), ssati = L(V_SSATI, k);
-            const double diffu = iiwarm ? 0. : L(V_DIFFU, k);
+            const double ni = ni_b, nr = L(V_NR, k);
+            const double ssatw = L(V_SSATW, k);
             const double nc = L_qc ? Nt_c : 2.;
 
             // cheap thermodynamics of block C recomputed here, M:1504-1532
@@ -622,7 +646,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 
             // ---- D: snow moments, M:1546-1627 ----
             double smob = 0., smo0 = 0., smo1 = 0., smoc = 0., smoe = 0., smof = 0.;
-            if (!iiwarm && L_qs) {
+            if constexpr (!iiwarm) if (L_qs) {
                 const double tc0 = fmin(-0.1, temp - 273.15);
                 smob = rs * kc::oams;
                 const Log2Parts lsmo2 = log2_parts(smob);    // smo2 = smob since bm_s == 2 (M:1553-1554)
@@ -645,7 +669,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 
             // ---- E (per level part): graupel slope/intercept, M:1650-1653 ----
             double ilamg = 0., N0_g = 0., ig_bv = 0., ig11 = 0.;
-            if (!iiwarm) {
+            if constexpr (!iiwarm) {
                 const double N0_exp = L(V_N0X, k);
                 const double lam_exp = root4(N0_exp * am_g * kc::cgg[0] / rg);
                 const double lamg = lam_exp * kc::lamg_fac;
@@ -1010,8 +1034,8 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             }
 
             // inputs of block J: requested now, consumed after the limiters
-            const double nc1_raw = L(V_NCRAW, k), ni1_raw = L(V_NIRAW, k), nr1_raw = L(V_NRRAW, k);
-            const double qc1 = L(V_RC, k), qi1 = L(V_RI, k), qr1 = L(V_RR, k);
+            const double nc1_raw = L(V_NCRAW, k), nr1_raw = L(V_NRRAW, k);
+            const double qc1 = L(V_RC, k), qi1 = qi1c, qr1 = L(V_RR, k);
 
             // ---- I: conservation limiters, M:2297-2385 ----
             {
@@ -1230,7 +1254,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 
             // ---- L: snow moments needed later (smoc/smob only), M:2663-2698 ----
             double xDs = 0.;
-            if (!iiwarm && (f2 & F_QS)) {
+            if constexpr (!iiwarm) if (f2 & F_QS) {
                 const double tc0 = fmin(-0.1, temp - 273.15);
                 const double smob = rs * kc::oams;
                 const double smoc = snow_moment(log2_parts(smob), tc0, kc::cse[0]);
@@ -1345,19 +1369,21 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
             L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
             L(V_QITEN, k) = qiten; L(V_NITEN, k) = niten; L(V_QSTEN, k) = qsten; L(V_QGTEN, k) = qgten;
-            L(V_BOOST, k) = boost_J;
-            L(V_TEMP2, k) = temp;  L(V_RHO2, k) = rho;    L(V_RI2, k) = ri;  L(V_NI2, k) = ni;
-            L(V_RR2, k) = rr;      L(V_NR2, k) = nr;      L(V_RS2, k) = rs;  L(V_RG2, k) = rg;
-            L(V_XDS, k) = xDs;     L(V_OCP, k) = ocp;     L(V_LVAP, k) = lvap;
+            L(V_RHO2, k) = rho;    L(V_RR2, k) = rr;      L(V_NR2, k) = nr;
+            if constexpr (!iiwarm) {
+                L(V_BOOST, k) = boost_J;  L(V_TEMP2, k) = temp;  L(V_RI2, k) = ri;  L(V_NI2, k) = ni;
+                L(V_RS2, k) = rs;      L(V_RG2, k) = rg;      L(V_XDS, k) = xDs;  L(V_OCP, k) = ocp;  L(V_LVAP, k) = lvap;
+            }
             }   // blocks K-N
             }   // valid (column, level)
             __builtin_amdgcn_wave_barrier();
         }
 
 #undef L
-#define L(slot, k) Lw[(slot) * NL + (k)]
+#define L(slot, k) Lw[slot_of<WARM, slot>() * NL + (k)]
+#define LR(slot, k) Lw[(slot) * NL + (k)]            // physical slot number (run-time slots of the frozen-species code)
         if (CPW > 1) __syncthreads();                        // S1/S2 images (and the scratch profile) complete
-        if (a.debug_stop == 3) { if (alive && lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
+        if (a.debug_stop == 3) { if (alive && lane == 0) kargs()->ppt[col * 4] += LR(0, 0) + LR(12, 1); return; }   // profiling aid only
         if (!alive) return;
         // Everything the remaining passes read from memory is requested here, in one round trip that the fall-speed
         // and sedimentation passes hide: dz and the block-K rain mvd (pass 3), and the column's state as block B
@@ -1395,7 +1421,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             dzv[j] = pf_dz[j];
             odz[j] = 1. / dzv[j];
             orho_[j] = 1. / rho;
-            tmp2[j] = L(V_TEMP2, k);
+            if constexpr (!iiwarm) tmp2[j] = L(V_TEMP2, k);
             const double rr = L(V_RR2, k);
             const double rhof = fm::sqrt_pos(rho_not / rho);
             rhofv[j] = rhof;
@@ -1432,7 +1458,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
         double n0x2[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) n0x2[j] = gonv_max;
-        if (!iiwarm) {
+        if constexpr (!iiwarm) {
             // graupel slope from the second running minimum, M:2717-2737
             {
                 int k0l = 0;
@@ -1589,7 +1615,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             ns[col * 4 + 2] = nstep_s; ns[col * 4 + 3] = nstep_g;
         }
 
-        if (a.debug_stop == 4) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
+        if (a.debug_stop == 4) { if (lane == 0) kargs()->ppt[col * 4] += LR(0, 0) + LR(12, 1); return; }   // profiling aid only
         // ============ pass 4: sedimentation sweeps, M:3365-3578 ============
         double ppt_r = 0., ppt_s = 0., ppt_g = 0., ppt_i = 0.;
         {   // rain (never gated by l_sediment), M:3365-3399
@@ -1626,7 +1652,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
                 if (k < nzu) { L(V_QRTEN, k) = qt[j]; L(V_NRTEN, k) = nt[j]; }
             }
         }
-        if (!iiwarm && c.l_sediment) {
+        if constexpr (!iiwarm) if (c.l_sediment) {
             {   // ice, M:3447-3480
                 double r[NJ], n[NJ], qt[NJ], nt[NJ], sr[NJ], sn[NJ], ur[NJ], un[NJ];
 #pragma unroll
@@ -1671,8 +1697,8 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
                 for (int j = 0; j < NJ; ++j) {
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                     const bool in = k < nzu;
-                    r[j] = in ? L(slot_r, k) : 0.;
-                    qt[j] = in ? L(slot_t, k) : 0.;
+                    r[j] = in ? LR(slot_r, k) : 0.;
+                    qt[j] = in ? LR(slot_t, k) : 0.;
                 }
                 for (int s = 0; s < nst; ++s) {
 #pragma unroll
@@ -1691,7 +1717,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
-                    if (k < nzu) L(slot_t, k) = qt[j];
+                    if (k < nzu) LR(slot_t, k) = qt[j];
                 }
                 if (sp == 0) ppt_s = pp; else ppt_g = pp;
             }
@@ -1704,7 +1730,7 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             pp[3] = pp[3] + ppt_i;
         }
 
-        if (a.debug_stop == 5) { if (lane == 0) kargs()->ppt[col * 4] += L(0, 0) + L(12, 1); return; }   // profiling aid only
+        if (a.debug_stop == 5) { if (lane == 0) kargs()->ppt[col * 4] += LR(0, 0) + LR(12, 1); return; }   // profiling aid only
         // ============ pass 5: blocks Q + R, M:3584-3686 (inputs requested before pass 3) ============
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -1720,9 +1746,10 @@ __global__ __launch_bounds__(CPW *WAVE, 2) void thompson_column_step(const StepA
             double tten = L(V_TTEN, k), qcten = L(V_QCTEN, k), ncten = L(V_NCTEN, k);
             double qiten = L(V_QITEN, k), niten = L(V_NITEN, k);
             const double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k), qsten = L(V_QSTEN, k), qgten = L(V_QGTEN, k);
-            const double temp = L(V_TEMP2, k), rho = L(V_RHO2, k), ocp = L(V_OCP, k), lvap = L(V_LVAP, k);
+            const double rho = L(V_RHO2, k);
 
-            if (!iiwarm) {                                   // Q, M:3585-3605
+            if constexpr (!iiwarm) {                         // Q, M:3585-3605
+                const double temp = L(V_TEMP2, k), ocp = L(V_OCP, k), lvap = L(V_LVAP, k);
                 const double xri = fmax(0.0, qi1 + qiten * DT);
                 if ((temp > T_0) && (xri > 0.0)) {
                     qcten = qcten + xri * odt;
