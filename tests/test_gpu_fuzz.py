@@ -88,3 +88,20 @@ def test_fuzz_warm(gpu_warm, oracle_warm):
         scale = np.maximum(np.maximum(np.abs(ref[k]), FLOORS[k]), 1e-5 * np.abs(st[k]))
         assert float(np.where(mask, np.abs(got[k] - ref[k]) / scale, 0.0).max()) < 1e-5, k
     assert float(np.max(np.abs(gppt - rppt) / np.maximum(np.abs(rppt), 1e-12))) < 1e-5
+
+
+def test_fuzz_warm_with_frozen_species_present(gpu_warm, oracle_warm):
+    """iiwarm skips the frozen-species PROCESSES (M:1749, M:3585), not the species: block B still cleans them,
+    block J rebalances the ice number and block R applies the final size limits.  The warm-rain kernel does not
+    stage them in LDS (it reads them again where needed), so feed it columns that do carry ice, snow and graupel."""
+    st = fuzz_columns(400, 120, 12)
+    ref = {k: v.copy() for k, v in st.items()}
+    rppt = oracle_warm.batch_step(ref, 10.0)
+    mask = conditioned_mask(oracle_warm, st, 10.0, ref)
+    got = {k: v.copy() for k, v in st.items()}
+    gppt, _ = gpu_warm.batch_step_host(got, 10.0)
+    for k in OUT:
+        scale = np.maximum(np.maximum(np.abs(ref[k]), FLOORS[k]), 1e-5 * np.abs(st[k]))
+        assert float(np.where(mask, np.abs(got[k] - ref[k]) / scale, 0.0).max()) < 1e-5, k
+    assert float(np.max(np.abs(gppt - rppt) / np.maximum(np.abs(rppt), 1e-12))) < 1e-5
+    assert (st["qi"] > 1e-12).any() and np.array_equal(got["qs"] > 0, st["qs"] > 1e-12)   # snow only cleaned, M:1475-1483
