@@ -318,7 +318,7 @@ enum Slot {
     V_PRRGML, V_BOOST,
     // S2 (written at the end of pass 2): keeps the tendencies, drops qvten / prr_gml
     V_OCP = V_QVTEN, V_LVAP = V_PRRGML,
-    V_TEMP2 = 12, V_RHO2, V_RI2, V_NI2, V_RR2, V_NR2, V_RS2, V_RG2, V_XDS,
+    V_TEMP2 = 12, V_RHO2, V_RI2, V_NI2, V_RR2, V_NR2, V_RS2, V_RG2, V_VTS0,
     NSLOT = 21
 };
 
@@ -1372,7 +1372,25 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             L(V_RHO2, k) = rho;    L(V_RR2, k) = rr;      L(V_NR2, k) = nr;
             if constexpr (!iiwarm) {
                 L(V_BOOST, k) = boost_J;  L(V_TEMP2, k) = temp;  L(V_RI2, k) = ri;  L(V_NI2, k) = ni;
-                L(V_RS2, k) = rs;      L(V_RG2, k) = rg;      L(V_XDS, k) = xDs;  L(V_OCP, k) = ocp;  L(V_LVAP, k) = lvap;
+                L(V_RS2, k) = rs;      L(V_RG2, k) = rg;      L(V_OCP, k) = ocp;  L(V_LVAP, k) = lvap;
+                // snow's mass-weighted fall speed without the riming boost, M:3290-3303: pointwise in k, so it is
+                // taken here, where the lanes of a wave share an altitude, and not in the per-column fall-speed pass
+                double vts0 = 0.;
+                if (rs > R1) {
+                    const double rhof_s = fm::sqrt_pos(rho_not / rho);
+                    const double Mrat = 1. / xDs;
+                    double ils1 = 1. / (Mrat * Lam0 + fv_s);
+                    double ils2 = 1. / (Mrat * Lam1 + fv_s);
+                    const double mm = fpow(Mrat, mu_s);
+                    const double t1_vts = Kap0 * kc::csg[3] * fpow(ils1, kc::cse[3]);
+                    const double t2_vts = Kap1 * mm * kc::csg[9] * fpow(ils2, kc::cse[9]);
+                    ils1 = 1. / (Mrat * Lam0);
+                    ils2 = 1. / (Mrat * Lam1);
+                    const double t3_vts = Kap0 * kc::csg[0] * cube(ils1);          // **cse(1), cse(1) = bm_s+1 = 3
+                    const double t4_vts = Kap1 * mm * kc::csg[6] * fpow(ils2, kc::cse[6]);
+                    vts0 = rhof_s * av_s * (t1_vts + t2_vts) / (t3_vts + t4_vts);
+                }
+                L(V_VTS0, k) = vts0;
             }
             }   // blocks K-N
             }   // valid (column, level)
@@ -1529,19 +1547,7 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                 if (k >= nzu) continue;
                 if (L(V_RS2, k) > R1) {
                     ok[j] = 1;
-                    const double rhof = rhofv[j];
-                    const double xDs = L(V_XDS, k);
-                    const double Mrat = 1. / xDs;
-                    double ils1 = 1. / (Mrat * Lam0 + fv_s);
-                    double ils2 = 1. / (Mrat * Lam1 + fv_s);
-                    const double mm = fpow(Mrat, mu_s);
-                    const double t1_vts = Kap0 * kc::csg[3] * fpow(ils1, kc::cse[3]);
-                    const double t2_vts = Kap1 * mm * kc::csg[9] * fpow(ils2, kc::cse[9]);
-                    ils1 = 1. / (Mrat * Lam0);
-                    ils2 = 1. / (Mrat * Lam1);
-                    const double t3_vts = Kap0 * kc::csg[0] * cube(ils1);          // **cse(1), cse(1) = bm_s+1 = 3
-                    const double t4_vts = Kap1 * mm * kc::csg[6] * fpow(ils2, kc::cse[6]);
-                    const double v = rhof * av_s * (t1_vts + t2_vts) / (t3_vts + t4_vts);
+                    const double v = L(V_VTS0, k);           // mass-weighted fall speed before the boost, from pass 1
                     const double boost = L(V_BOOST, k);
                     if (tmp2[j] > (T_0 + 0.1))
                         vts[j] = fmax(v * boost, v * ((vtr[j] - v * boost) / (tmp2[j] - T_0)));
@@ -1627,6 +1633,11 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                 r[j] = in ? L(V_RR2, k) : 0.;   n[j] = in ? L(V_NR2, k) : 0.;
                 qt[j] = in ? L(V_QRTEN, k) : 0.; nt[j] = in ? L(V_NRTEN, k) : 0.;
             }
+            // per-level weights of a substep: odzq*onstep*orho for the tendency, odzq*DT*onstep for the content
+            // (the reference multiplies them in one by one, M:3380-3387; hoisting them differs in the last bit)
+            double wten_r[NJ], wcon_r[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { wten_r[j] = odz[j] * onstep_r * orho_[j]; wcon_r[j] = odz[j] * DT * onstep_r; }
             for (int s = 0; s < nstep_r; ++s) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) { sr[j] = vtr[j] * r[j]; sn[j] = vtnr[j] * n[j]; }
@@ -1638,10 +1649,18 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                     // the top level (M:3370-3377) is the general update with nothing falling in: ur = un = 0 there
                     // (the slot above holds r = 0), and q - x == q + (0 - x) bit for bit
                     if (k == kteu || int(k) <= ksed_r) {
-                        qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_r * orho_[j];
-                        nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_r * orho_[j];
-                        r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_r);
-                        n[j] = fmax(R2, n[j] + (un[j] - sn[j]) * odz[j] * DT * onstep_r);
+                        const double dq = ur[j] - sr[j], dn = un[j] - sn[j];
+                        if constexpr (iiwarm) {              // one or two substeps: the reference's product order
+                            qt[j] = qt[j] + dq * odz[j] * onstep_r * orho_[j];
+                            nt[j] = nt[j] + dn * odz[j] * onstep_r * orho_[j];
+                            r[j] = fmax(R1, r[j] + dq * odz[j] * DT * onstep_r);
+                            n[j] = fmax(R2, n[j] + dn * odz[j] * DT * onstep_r);
+                        } else {                             // many substeps: per-level weights hoisted out of the loop
+                            qt[j] = qt[j] + dq * wten_r[j];
+                            nt[j] = nt[j] + dn * wten_r[j];
+                            r[j] = fmax(R1, r[j] + dq * wcon_r[j]);
+                            n[j] = fmax(R2, n[j] + dn * wcon_r[j]);
+                        }
                     }
                 }
                 if (r[0] > R1 * 10.) ppt_r = ppt_r + sr[0] * DT * onstep_r;   // meaningful on lane 0 (k = kts)
@@ -1662,6 +1681,9 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                     r[j] = in ? L(V_RI2, k) : 0.;   n[j] = in ? L(V_NI2, k) : 0.;
                     qt[j] = in ? L(V_QITEN, k) : 0.; nt[j] = in ? L(V_NITEN, k) : 0.;
                 }
+                double wten_i[NJ], wcon_i[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { wten_i[j] = odz[j] * onstep_i * orho_[j]; wcon_i[j] = odz[j] * DT * onstep_i; }
                 for (int s = 0; s < nstep_i; ++s) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) { sr[j] = vti[j] * r[j]; sn[j] = vtni[j] * n[j]; }
@@ -1671,10 +1693,11 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                     for (int j = 0; j < NJ; ++j) {
                         const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                         if (k == kteu || int(k) <= ksed_i) {     // top level: as for rain
-                            qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onstep_i * orho_[j];
-                            nt[j] = nt[j] + (un[j] - sn[j]) * odz[j] * onstep_i * orho_[j];
-                            r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onstep_i);
-                            n[j] = fmax(R2, n[j] + (un[j] - sn[j]) * odz[j] * DT * onstep_i);
+                            const double dq = ur[j] - sr[j], dn = un[j] - sn[j];
+                            qt[j] = qt[j] + dq * wten_i[j];
+                            nt[j] = nt[j] + dn * wten_i[j];
+                            r[j] = fmax(R1, r[j] + dq * wcon_i[j]);
+                            n[j] = fmax(R2, n[j] + dn * wcon_i[j]);
                         }
                     }
                     if (r[0] > R1 * 10.) ppt_i = ppt_i + sr[0] * DT * onstep_i;
@@ -1700,6 +1723,9 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                     r[j] = in ? LR(slot_r, k) : 0.;
                     qt[j] = in ? LR(slot_t, k) : 0.;
                 }
+                double wten[NJ], wcon[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { wten[j] = odz[j] * onst * orho_[j]; wcon[j] = odz[j] * DT * onst; }
                 for (int s = 0; s < nst; ++s) {
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) sr[j] = (sp == 0 ? vts[j] : vtg[j]) * r[j];
@@ -1708,8 +1734,9 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                     for (int j = 0; j < NJ; ++j) {
                         const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                         if (k == kteu || int(k) <= ksed) {
-                            qt[j] = qt[j] + (ur[j] - sr[j]) * odz[j] * onst * orho_[j];
-                            r[j] = fmax(R1, r[j] + (ur[j] - sr[j]) * odz[j] * DT * onst);
+                            const double dq = ur[j] - sr[j];
+                            qt[j] = qt[j] + dq * wten[j];
+                            r[j] = fmax(R1, r[j] + dq * wcon[j]);
                         }
                     }
                     if (r[0] > R1 * 10.) pp = pp + sr[0] * DT * onst;
