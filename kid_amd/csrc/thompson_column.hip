@@ -430,6 +430,7 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
         int pst[NJ];              // per level group: bits 0-4 L_q* of block B, bits 8-12 L_q* of block K, bit 16 T >= 270.65
         double mvdB[NJ], rgB[NJ];
         bool any_micro = false;
+        bool col_frozen = true;   // warm-rain kernel: false if the column's frozen species are all exactly zero
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { pst[j] = 0; mvdB[j] = 0.; rgB[j] = R1; }
         if (alive) {
@@ -451,6 +452,15 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             i_qr[j] = gqr[kc]; i_qs[j] = gqs[kc]; i_qg[j] = gqg[kc]; i_ni[j] = gni[kc]; i_nr[j] = gnr[kc];
             i_nc[j] = gnc[kc]; i_nwfa[j] = gnwfa[kc]; i_nifa[j] = gnifa[kc];
         }
+        }
+        // Warm-rain kernel: a column whose frozen species are exactly zero on input (the normal KiD warm case,
+        // W:46-52) keeps them exactly zero, so pass 1 need not read them again and pass 5 need neither read nor
+        // write them (bit-identical result, a third less memory traffic).
+        if constexpr (iiwarm) {
+            bool fz = false;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fz = fz || i_qi[j] != 0. || i_qs[j] != 0. || i_qg[j] != 0. || i_ni[j] != 0.;
+            col_frozen = __any(fz);                          // lanes beyond nz hold copies of the top level
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -543,9 +553,8 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                 const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
                 if (k >= nzu) continue;
                 gqc[k] = 0.0; gnc[k] = 0.0;
-                gqi[k] = 0.0; gni[k] = 0.0;
                 gqr[k] = 0.0; gnr[k] = 0.0;
-                gqs[k] = 0.0; gqg[k] = 0.0;
+                if (col_frozen) { gqi[k] = 0.0; gni[k] = 0.0; gqs[k] = 0.0; gqg[k] = 0.0; }
                 if (RATES)
                     for (int r = 0; r < KIDMP_NRATES_; ++r) grates[int64_t(r) * nz + k] = 0.;
             }
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
         }   // alive: pass 0
         if (a.debug_stop == 1) { if (alive && lane == 0) kargs()->ppt[col * 4] += LR(0, 0) + LR(12, 1); return; }   // profiling aid only
         if (CPW > 1) {
-            if (lane == 0) s_alive[wv] = alive ? 1 : 0;
+            if (lane == 0) s_alive[wv] = alive ? (col_frozen ? 3 : 1) : 0;     // bit 1: frozen species present
             if (threadIdx.x == 0) s_next = 0;
             __syncthreads();                                 // S0 images of all CPW columns complete
         }
@@ -616,9 +625,12 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             // cleaned frozen-species inputs: from the LDS image, or (warm layout: not staged) again from memory
             double qi1c, qs1c, qg1c, ni_b = R2, ni1_raw, qvsi = 0., ssati = 0., diffu = 0.;
             if constexpr (iiwarm) {
-                const double rqi = gptr(ka1->qi, base0)[gk], rqs = gptr(ka1->qs, base0)[gk], rqg = gptr(ka1->qg, base0)[gk];
-                ni1_raw = gptr(ka1->ni, base0)[gk];
-                qi1c = rqi > R1 ? rqi : 0.;  qs1c = rqs > R1 ? rqs : 0.;  qg1c = rqg > R1 ? rqg : 0.;
+                qi1c = 0.; qs1c = 0.; qg1c = 0.; ni1_raw = 0.;
+                if (CPW == 1 ? col_frozen : (s_alive[cw] & 2) != 0) {
+                    const double rqi = gptr(ka1->qi, base0)[gk], rqs = gptr(ka1->qs, base0)[gk], rqg = gptr(ka1->qg, base0)[gk];
+                    ni1_raw = gptr(ka1->ni, base0)[gk];
+                    qi1c = rqi > R1 ? rqi : 0.;  qs1c = rqs > R1 ? rqs : 0.;  qg1c = rqg > R1 ? rqg : 0.;
+                }
             } else {
                 qi1c = L(V_RI, k);  qs1c = L(V_RS, k);  qg1c = L(V_RG, k);
                 ni_b = L(V_NI, k);  ni1_raw = L(V_NIRAW, k);
@@ -1418,8 +1430,9 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             const unsigned kc = k < nzu ? k : kteu;
             pf_dz[j] = gdz[kc]; pf_scr[j] = gscr[kc];
-            o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qr[j] = gqr[kc];
-            o_nr[j] = gnr[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc]; o_t[j] = gt[kc];
+            o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qr[j] = gqr[kc]; o_nr[j] = gnr[kc]; o_t[j] = gt[kc];
+            o_qi[j] = 0.; o_ni[j] = 0.; o_qs[j] = 0.; o_qg[j] = 0.;
+            if (col_frozen) { o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc]; }
         }
         // ============ pass 3: fall speeds, M:3206-3354 ============
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
@@ -1828,8 +1841,7 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
                 else if (xDi > 300.E-6)   lami = kc::cie[1] / 300.E-6;
                 nin = fmin(kc::cig[0] * kc::oig2 * qi / am_i * cube(lami), 499.e3 / rho);
             }
-            gqi[k] = qi;
-            gni[k] = nin;
+            if (col_frozen) { gqi[k] = qi; gni[k] = nin; }
 
             double qr = qr1 + qrten * DT;
             double nrn = fmax(R2 / rho, nr1 + nrten * DT);
@@ -1847,9 +1859,8 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             gnr[k] = nrn;
 
             const double qs = qs1 + qsten * DT;
-            gqs[k] = qs <= R1 ? 0.0 : qs;
             const double qg = qg1 + qgten * DT;
-            gqg[k] = qg <= R1 ? 0.0 : qg;
+            if (col_frozen) { gqs[k] = qs <= R1 ? 0.0 : qs; gqg[k] = qg <= R1 ? 0.0 : qg; }
         }
     }
 }
