@@ -1262,7 +1262,7 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             if ((qg1 + qgten * DT) > R1) { rg = (qg1 + qgten * DT) * rho; f2 |= F_QG; }
             // for the second graupel-intercept scan (pass 3, M:2717-2737): rain mvd of block K (0: no rain), with
             // "temp >= 270.65" (k_0 of M:2718-2721) in the sign bit.  It crosses waves, so it goes through memory.
-            gptr(kargs()->scratch, base0)[gk] = temp >= 270.65 ? -mvdK : mvdK;
+            if constexpr (!iiwarm) gptr(kargs()->scratch, base0)[gk] = temp >= 270.65 ? -mvdK : mvdK;
 
             // ---- L: snow moments needed later (smoc/smob only), M:2663-2698 ----
             double xDs = 0.;
@@ -1429,7 +1429,9 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
         for (int j = 0; j < NJ; ++j) {
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             const unsigned kc = k < nzu ? k : kteu;
-            pf_dz[j] = gdz[kc]; pf_scr[j] = gscr[kc];
+            pf_dz[j] = gdz[kc];
+            pf_scr[j] = 0.;
+            if constexpr (!iiwarm) pf_scr[j] = gscr[kc];     // only the graupel intercept scan reads it
             o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qr[j] = gqr[kc]; o_nr[j] = gnr[kc]; o_t[j] = gt[kc];
             o_qi[j] = 0.; o_ni[j] = 0.; o_qs[j] = 0.; o_qg[j] = 0.;
             if (col_frozen) { o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc]; }
