@@ -104,6 +104,21 @@ def test_rates_match_oracle(gpu_mixed, oracle_mixed):
         assert np.max(err) < 1e-8, (c, float(np.max(err)), int(np.argmax(np.max(err, axis=1))))
 
 
+def test_rates_match_oracle_warm(gpu_warm, oracle_warm):
+    """The warm-rain instantiation with the rate buffer: the 6 warm rates of M:3104-3119, zeros for the other 30."""
+    st = cases.replicate(kc.kat_a(False), 3)
+    st["qr"][1] *= 3.0
+    st["qc"][2] *= 0.3
+    got, gppt, rates = _gpu_batch(gpu_warm, st, 10.0, rates=True)
+    for c in range(3):
+        col = {k: st[k][c].copy() for k in st}
+        _, rref, _, _ = oracle_warm.column_step(col, 10.0, want_rates=True)
+        scale = np.maximum(np.max(np.abs(rref), axis=1, keepdims=True), 1e-300)
+        err = np.abs(rates[c] - rref) / np.maximum(np.abs(rref), 1e-9 * scale)
+        assert np.max(err) < 1e-8, (c, float(np.max(err)), int(np.argmax(np.max(err, axis=1))))
+        assert np.count_nonzero(rates[c][:30]) == 0 and np.count_nonzero(rates[c][30:]) > 0
+
+
 def test_kat_c_sedimentation_substeps(gpu_mixed, oracle_mixed):
     import torch
     st = cases.replicate(kc.kat_c(), 2)
