@@ -21,10 +21,18 @@
 //       - upwind flux sed(k+1)               lane shift      (M:3381...)
 //   * lookup tables stay in HBM/Infinity Cache; the rain-snow / rain-graupel /
 //     rain-freezing families are read as interleaved per-cell records.
+//   * a workgroup is four waves = four consecutive columns.  The pointwise
+//     rate sweep (blocks D-N, 60 % of the instructions) is shared out by
+//     ALTITUDE BAND instead: one wave pass = 16 levels of all four columns,
+//     so the lanes of a pass sit in one microphysical regime (see the kernel).
+//   * two instantiations: mixed phase (256 VGPRs, 21 LDS slots, 2 waves per
+//     SIMD) and warm rain (iiwarm contexts: frozen-species blocks compiled
+//     out, 168 VGPRs, 13 slots, 3 waves per SIMD).
 // No MFMA: pointwise transcendental rates plus a vertical sweep.
 //
 // Arithmetic: fp64 throughout (the reference's P64 build), compiled with
-// -ffp-contract=off so products and sums round as in the Fortran.
+// -ffp-contract=off so products and sums round as in the Fortran.  libm calls
+// are fastmath.h (range-specific, <= ~2 ulp); division is rcp + Newton (<= 1 ulp).
 //
 // Reference UB given defined semantics (same decisions as the oracle):
 //   U1 cloud water does not sediment (vtck/vtnck never assigned, M:3414-3425).
