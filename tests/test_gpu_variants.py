@@ -57,6 +57,16 @@ def test_other_level_counts(gpu_mixed, oracle_mixed, nz):
     _compare(gpu_mixed, oracle_mixed, _batch(cols), 10.0)
 
 
+@pytest.mark.parametrize("nz", [2, 33, 64, 65, 120, 121, 128, 190, 256])
+def test_other_level_counts_warm(gpu_warm, oracle_warm, nz):
+    """The warm-rain instantiation (13-slot LDS layout) at every level-group count / LDS stride, with and without
+    frozen species in the input (it reads them again from memory where the mixed-phase kernel has them in LDS)."""
+    cols = [_resample(kc.kat_a(False), nz), _resample(kc.kat_a(True), nz), _resample(kc.kat_c(), nz),
+            _resample(kc.kat_a(False), nz), _resample(kc.kat_a(False), nz)]
+    cols[3]["qr"] = cols[3]["qr"] * 4.0
+    _compare(gpu_warm, oracle_warm, _batch(cols), 10.0)
+
+
 @pytest.mark.parametrize("dt", [1.0, 5.0, 30.0, 60.0, 150.0])
 def test_other_time_steps(gpu_mixed, oracle_mixed, dt):
     st = cases.edge_cases()
