@@ -206,7 +206,7 @@ def main():
             "precip_domain_sums": [float(x) for x in diag.cpu().tolist()],
             "init_seconds": model.init_seconds,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (the host cores are shared by the ranks)
             out["cpu_baseline"] = cpu_baseline(model, st, iiwarm)
         print(json.dumps(out))
     if world > 1:
