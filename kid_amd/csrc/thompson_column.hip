@@ -632,9 +632,10 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             CArgs *ka1 = kargs();
             // cleaned frozen-species inputs: from the LDS image, or (warm layout: not staged) again from memory
             double qi1c, qs1c, qg1c, ni_b = R2, ni1_raw, qvsi = 0., ssati = 0., diffu = 0.;
+            const bool frozen_here = !iiwarm || (CPW == 1 ? col_frozen : (s_alive[cw] & 2) != 0);   // this lane's column
             if constexpr (iiwarm) {
                 qi1c = 0.; qs1c = 0.; qg1c = 0.; ni1_raw = 0.;
-                if (CPW == 1 ? col_frozen : (s_alive[cw] & 2) != 0) {
+                if (frozen_here) {
                     const double rqi = gptr(ka1->qi, base0)[gk], rqs = gptr(ka1->qs, base0)[gk], rqg = gptr(ka1->qg, base0)[gk];
                     ni1_raw = gptr(ka1->ni, base0)[gk];
                     qi1c = rqi > R1 ? rqi : 0.;  qs1c = rqs > R1 ? rqs : 0.;  qg1c = rqg > R1 ? rqg : 0.;
@@ -1388,7 +1389,14 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
 
             L(V_TTEN, k) = tten;   L(V_QCTEN, k) = qcten; L(V_NCTEN, k) = ncten;
             L(V_QRTEN, k) = qrten; L(V_NRTEN, k) = nrten;
-            L(V_QITEN, k) = qiten; L(V_NITEN, k) = niten; L(V_QSTEN, k) = qsten; L(V_QGTEN, k) = qgten;
+            if (frozen_here) {
+                L(V_QITEN, k) = qiten; L(V_NITEN, k) = niten; L(V_QSTEN, k) = qsten; L(V_QGTEN, k) = qgten;
+            } else {
+                // warm column without frozen species: those four tendencies are exactly zero, and their slots carry
+                // the cleaned inputs pass 5 adds the tendencies to, so that it does not read them from memory again
+                L(V_QITEN, k) = qc1;   L(V_NITEN, k) = nc1;   L(V_QSTEN, k) = qr1;   L(V_QGTEN, k) = nr1;
+            }
+            if constexpr (iiwarm) L(V_QVTEN, k) = t1;        // the input temperature, likewise (slot free once qv is read)
             L(V_RHO2, k) = rho;    L(V_RR2, k) = rr;      L(V_NR2, k) = nr;
             if constexpr (!iiwarm) {
                 L(V_BOOST, k) = boost_J;  L(V_TEMP2, k) = temp;  L(V_RI2, k) = ri;  L(V_NI2, k) = ni;
@@ -1440,9 +1448,13 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             pf_dz[j] = gdz[kc];
             pf_scr[j] = 0.;
             if constexpr (!iiwarm) pf_scr[j] = gscr[kc];     // only the graupel intercept scan reads it
-            o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qr[j] = gqr[kc]; o_nr[j] = gnr[kc]; o_t[j] = gt[kc];
+            o_qc[j] = o_nc[j] = o_qr[j] = o_nr[j] = o_t[j] = 0.;
             o_qi[j] = 0.; o_ni[j] = 0.; o_qs[j] = 0.; o_qg[j] = 0.;
-            if (col_frozen) { o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc]; }
+            if (col_frozen) {                               // (always, in the mixed-phase kernel)
+                o_qc[j] = gqc[kc]; o_nc[j] = gnc[kc]; o_qr[j] = gqr[kc]; o_nr[j] = gnr[kc];
+                o_qi[j] = gqi[kc]; o_ni[j] = gni[kc]; o_qs[j] = gqs[kc]; o_qg[j] = gqg[kc];
+                if constexpr (!iiwarm) o_t[j] = gt[kc];
+            }
         }
         // ============ pass 3: fall speeds, M:3206-3354 ============
         double vtr[NJ], vtnr[NJ], vti[NJ], vtni[NJ], vts[NJ], vtg[NJ];
@@ -1787,15 +1799,20 @@ __global__ __launch_bounds__(CPW *WAVE, WARM ? 3 : 2) void thompson_column_step(
             const unsigned k = unsigned(lane) + unsigned(WAVE) * unsigned(j);
             if (k >= nzu) continue;
             const int f = pst[j] & 31;
-            const double rqc = o_qc[j], rnc = o_nc[j], rqi = o_qi[j], rni = o_ni[j], rqr = o_qr[j], rnr = o_nr[j],
-                         rqs = o_qs[j], rqg = o_qg[j], t1 = o_t[j];     // cleaned below (block B)
+            double rqc = o_qc[j], rnc = o_nc[j], rqr = o_qr[j], rnr = o_nr[j], t1 = o_t[j];
+            const double rqi = o_qi[j], rni = o_ni[j], rqs = o_qs[j], rqg = o_qg[j];         // cleaned below (block B)
+            if constexpr (iiwarm) {
+                t1 = L(V_QVTEN, k);
+                if (!col_frozen) { rqc = L(V_QITEN, k); rnc = L(V_NITEN, k); rqr = L(V_QSTEN, k); rnr = L(V_QGTEN, k); }
+            }
             const double qc1 = (f & F_QC) ? rqc : 0.0, nc1 = (f & F_QC) ? rnc : 0.0;
             const double qi1 = (f & F_QI) ? rqi : 0.0, ni1 = (f & F_QI) ? rni : 0.0;
             const double qr1 = (f & F_QR) ? rqr : 0.0, nr1 = (f & F_QR) ? rnr : 0.0;
             const double qs1 = (f & F_QS) ? rqs : 0.0, qg1 = (f & F_QG) ? rqg : 0.0;
             double tten = L(V_TTEN, k), qcten = L(V_QCTEN, k), ncten = L(V_NCTEN, k);
-            double qiten = L(V_QITEN, k), niten = L(V_NITEN, k);
-            const double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k), qsten = L(V_QSTEN, k), qgten = L(V_QGTEN, k);
+            double qiten = 0., niten = 0., qsten = 0., qgten = 0.;
+            if (col_frozen) { qiten = L(V_QITEN, k); niten = L(V_NITEN, k); qsten = L(V_QSTEN, k); qgten = L(V_QGTEN, k); }
+            const double qrten = L(V_QRTEN, k), nrten = L(V_NRTEN, k);
             const double rho = L(V_RHO2, k);
 
             if constexpr (!iiwarm) {                         // Q, M:3585-3605
