@@ -15,6 +15,8 @@
  *     columns is x[col*nz + k].
  *   - Every function returns 0 on success or a negative KIDMP_E* code; it
  *     never aborts and never throws.  kidmp_last_error() gives the text.
+ *   - Every entry point makes the context's device current for the duration of the call and restores the
+ *     caller's; device pointers must belong to the context's device (KIDMP_EINVAL otherwise).
  *   - One context per process and device; calls on one context are
  *     serialised by the caller (the reference is single-threaded, M:386-430),
  *     and its asynchronous launches must not overlap on the device (enqueue
@@ -111,6 +113,19 @@ int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n,
 int kidmp_reduce_ppt_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt,
                             double *out4, void *stream);
 
+/* Optional domain diagnostics beyond the four precipitation sums.
+ * kidmp_reduce_rates_device: out[KIDMP_NRATES*nz] (device) = sum over columns of rates[col][r][k] -- the mean
+ *   process-rate profiles KiD plots are these sums / ncol (save_dg(k, value, ...) of M:2967-3119, averaged over nx);
+ *   fixed summation order, so the result is reproducible.  Multi-GPU callers all-reduce(SUM) it.
+ * kidmp_sanity_device: the scan the scheme's own 3-D driver runs after each column (M:1025-1094):
+ *   out15[0..6] = max over all n = ncol*nz entries of qc, qr, nr, qs, qi, qg, ni; out15[7..14] = how many entries of
+ *   qc, qr, nr, qs, qi, qg, ni, qv are negative (the reference formats a WARNING for each).  Multi-GPU callers
+ *   all-reduce(MAX) the first seven and all-reduce(SUM) the rest. */
+int kidmp_reduce_rates_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, const double *rates, double *out, void *stream);
+int kidmp_sanity_device(kidmp_ctx *ctx, int64_t n, const double *qc, const double *qr, const double *nr,
+                        const double *qs, const double *qi, const double *qg, const double *ni, const double *qv,
+                        double *out15, void *stream);
+
 /* Introspection for parity tests: copy a lookup table / constant array to the
  * host.  Names are the reference's (tcg_racg ... t_Efsw; cre, crg, Dr ...).
  * Returns the number of doubles (<0 on error); out may be NULL to query. */
@@ -146,6 +161,11 @@ double kidmp_init_seconds(const kidmp_ctx *ctx);
 
 /* Name of the column-step kernel as it appears in rocprofv3 traces. */
 const char *kidmp_kernel_name(void);
+
+/* Identifies the code object of this context's nz <= 120 column-step kernel:
+ * "src:<hash of the kernel sources and flags>;vgpr:<n>;lds:<bytes>;scratch:<bytes>".  Profiles under profiles/
+ * carry it, so a counter file measured on another build of the kernel is recognised as stale (bench.py). */
+const char *kidmp_kernel_fingerprint(kidmp_ctx *ctx);
 
 #ifdef __cplusplus
 }

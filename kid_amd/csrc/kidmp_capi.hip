@@ -40,6 +40,11 @@ struct kidmp_ctx {
     size_t scratch_elems = 0;
     int debug_stop = 0;
     int cslot = -1;
+    // partial sums of kidmp_reduce_rates_device, accumulators of kidmp_sanity_device
+    double *d_red = nullptr;
+    size_t red_elems = 0;
+    unsigned long long *d_sanity = nullptr;
+    std::string fingerprint;
 };
 
 namespace {
@@ -73,6 +78,40 @@ int hipfail(kidmp_ctx *c, hipError_t e, const char *what)
 }
 #define HIPTRY(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return hipfail((c), e_, #x); } while (0)
 
+// Every entry point that touches the device runs with the context's device current and puts the caller's
+// device back on exit: the caller (torch, a Fortran host driving several GPUs) may have another one selected,
+// and hipMalloc / kernel launches / the __constant__ slot all bind to the current device.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define GUARD(c) DeviceGuard guard_((c)->cfg.device); if (guard_.err != hipSuccess) return hipfail((c), guard_.err, "hipSetDevice")
+
+// A device pointer handed to a device entry must live on the context's GPU: a buffer of another GPU would be
+// reached through peer access at best and fault at worst.
+int check_on_device(kidmp_ctx *c, const void *p, const char *what)
+{
+    if (!p) return KIDMP_OK;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return KIDMP_OK; }   // unregistered: let the launch decide
+    if (at.type == hipMemoryTypeDevice && at.device != c->cfg.device)
+        return fail(c, KIDMP_EINVAL, std::string("kidmp: ") + what + " lives on device " + std::to_string(at.device)
+                                     + ", the context is bound to device " + std::to_string(c->cfg.device));
+    return KIDMP_OK;
+}
+
 __global__ void k_default_aerosols(int64_t n, double Nt_c, const double *__restrict__ qv, const double *__restrict__ t,
                                    const double *__restrict__ p, double *__restrict__ nc, double *__restrict__ nwfa,
                                    double *__restrict__ nifa)
@@ -100,6 +139,66 @@ __global__ void k_reduce_ppt(int64_t ncol, const double *__restrict__ ppt, doubl
         __syncthreads();
     }
     if (threadIdx.x < 4) out4[threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// Domain sums of the rate diagnostics: part[chunk][r*nz+k] = sum over the chunk's columns (fixed order), then
+// out[r*nz+k] = sum over chunks (fixed order) => bitwise reproducible for a given ncol.
+constexpr int RED_CHUNKS = 128;
+__global__ void k_reduce_rates_part(int64_t ncol, int n, const double *__restrict__ rates, double *__restrict__ part)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // r*nz + k
+    if (i >= n) return;
+    const int64_t per = (ncol + RED_CHUNKS - 1) / RED_CHUNKS;
+    const int64_t c0 = int64_t(blockIdx.y) * per, c1 = c0 + per < ncol ? c0 + per : ncol;
+    double acc = 0.;
+    for (int64_t c = c0; c < c1; ++c) acc += rates[c * n + i];
+    part[int64_t(blockIdx.y) * n + i] = acc;
+}
+__global__ void k_reduce_rates_final(int n, const double *__restrict__ part, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double acc = 0.;
+    for (int c = 0; c < RED_CHUNKS; ++c) acc += part[int64_t(c) * n + i];
+    out[i] = acc;
+}
+
+// The sanity scan the scheme's own 3-D driver runs after every column (M:1025-1094): running maxima of
+// qc, qr, nr, qs, qi, qg, ni and a look-out for negative values (there: WARNING strings; here: counts).
+// out[0..6] = maxima (>= 0), out[7..14] = number of negative entries of qc,qr,nr,qs,qi,qg,ni,qv.
+// Maxima of non-negative doubles order like their bit patterns, so both halves are exact integer atomics.
+struct SanityPtrs { const double *v[8]; };
+__global__ void k_sanity(int64_t n, SanityPtrs p, unsigned long long *acc)
+{
+    __shared__ unsigned long long sh[15];
+    if (threadIdx.x < 15) sh[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long mx[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned neg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const double x = p.v[a][i];
+            if (x < 0.) ++neg[a];
+            else if (a < 7) {
+                const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+                mx[a] = b > mx[a] && x == x ? b : mx[a];
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 7; ++a) atomicMax(&sh[a], mx[a]);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) if (neg[a]) atomicAdd(&sh[7 + a], (unsigned long long)neg[a]);
+    __syncthreads();
+    if (threadIdx.x < 7) atomicMax(&acc[threadIdx.x], sh[threadIdx.x]);
+    else if (threadIdx.x < 15 && sh[threadIdx.x]) atomicAdd(&acc[threadIdx.x], sh[threadIdx.x]);
+}
+__global__ void k_sanity_final(const unsigned long long *acc, double *out15)
+{
+    const int i = threadIdx.x;
+    if (i < 7) out15[i] = __longlong_as_double((long long)acc[i]);
+    else if (i < 15) out15[i] = double(acc[i]);
 }
 
 struct Named { const char *name; const double *ptr; int64_t n; };
@@ -220,12 +319,14 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
     kidmp_ctx *c = new (std::nothrow) kidmp_ctx;
     if (!c) return fail(nullptr, KIDMP_ENOMEM, "kidmp_init: out of host memory");
     c->cfg = *cfg;
-    if (const char *e = getenv("KIDMP_DEBUG_STOP")) c->debug_stop = atoi(e);   // profiling aid: truncates the step
+#ifdef KIDMP_PROFILING
+    if (const char *e = getenv("KIDMP_DEBUG_STOP")) c->debug_stop = atoi(e);   // libkidmp_prof.so only: truncates the step
+#endif
     const auto t0 = std::chrono::steady_clock::now();
     auto bail = [&](int code) { kidmp_finalize(c); return code; };
+    DeviceGuard guard_(cfg->device);                 // the caller's current device is restored on every exit path
     {
-        hipError_t e = hipSetDevice(cfg->device);
-        if (e != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return bail(KIDMP_EHIP); }
+        if (guard_.err != hipSuccess) { g_err = std::string("hipSetDevice: ") + hipGetErrorString(guard_.err); return bail(KIDMP_EHIP); }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && !strstr(prop.gcnArchName, "gfx950")) {
             g_err = std::string("kidmp_init: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only";
@@ -259,11 +360,14 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
 void kidmp_finalize(kidmp_ctx *c)
 {
     if (!c) return;
+    DeviceGuard guard_(c->cfg.device);
     free_tables(c->tables);
     if (c->d_consts) (void)hipFree(c->d_consts);
     if (c->d_bins) (void)hipFree(c->d_bins);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_red) (void)hipFree(c->d_red);
+    if (c->d_sanity) (void)hipFree(c->d_sanity);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     give_slot(c->cslot);
     delete c;
@@ -282,6 +386,9 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     (void)w;   // w1d only feeds activ_ncloud (is_aerosol_aware, M:2797)
     const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
     if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, qv, "qv")) return rc;
+    if (int rc = check_on_device(ctx, ppt, "ppt")) return rc;
     StepArgs a{};
     a.qv = qv; a.qc = qc; a.qi = qi; a.qr = qr; a.qs = qs; a.qg = qg; a.ni = ni; a.nr = nr;
     a.nc = nc; a.nwfa = nwfa; a.nifa = nifa; a.t = t; a.p = p; a.dz = dz;
@@ -300,7 +407,7 @@ int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
     if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return fail(ctx, KIDMP_EINVAL, "kidmp_reserve: bad argument");
-    HIPTRY(ctx, hipSetDevice(ctx->cfg.device));
+    GUARD(ctx);
     return ensure_scratch(ctx, ncol, nz);
 }
 
@@ -314,7 +421,7 @@ int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
     if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
     if (ncol == 0) return KIDMP_OK;
-    HIPTRY(ctx, hipSetDevice(ctx->cfg.device));
+    GUARD(ctx);
     const size_t prof = size_t(ncol) * size_t(nz);
     const size_t need = (14 * prof + 4 * size_t(ncol) + (rates ? size_t(KIDMP_NRATES) * prof : 0)) * sizeof(double);
     if (need > ctx->stage_bytes) {
@@ -359,6 +466,9 @@ int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n, const double *qv, c
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
     if (n < 0 || !qv || !t || !p || !nc || !nwfa || !nifa) return fail(ctx, KIDMP_EINVAL, "kidmp_default_aerosols_device: bad argument");
     if (n == 0) return KIDMP_OK;
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, qv, "qv")) return rc;
+    if (int rc = check_on_device(ctx, nc, "nc")) return rc;
     const int T = 256;
     hipLaunchKernelGGL(k_default_aerosols, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, (hipStream_t)stream, n,
                        ctx->hc.Nt_c, qv, t, p, nc, nwfa, nifa);
@@ -371,6 +481,7 @@ int kidmp_math_probe(kidmp_ctx *ctx, int32_t fn, int64_t n, const double *x, con
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
     if (n < 0 || !x || !y || !out || fn < 0 || fn > KIDMP_MATH_POW) return fail(ctx, KIDMP_EINVAL, "kidmp_math_probe: bad argument");
     if (n == 0) return KIDMP_OK;
+    GUARD(ctx);
     double *d = nullptr;
     HIPTRY(ctx, hipMalloc(&d, size_t(n) * 3 * sizeof(double)));
     hipError_t e = hipMemcpy(d, x, size_t(n) * sizeof(double), hipMemcpyHostToDevice);
@@ -389,14 +500,71 @@ int kidmp_reduce_ppt_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt, dou
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
     if (ncol < 0 || !ppt || !out4) return fail(ctx, KIDMP_EINVAL, "kidmp_reduce_ppt_device: bad argument");
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, ppt, "ppt")) return rc;
+    if (int rc = check_on_device(ctx, out4, "out4")) return rc;
     hipLaunchKernelGGL(k_reduce_ppt, dim3(1), dim3(256), 0, (hipStream_t)stream, ncol, ppt, out4);
     HIPTRY(ctx, hipGetLastError());
     return KIDMP_OK;
 }
 
+int kidmp_reduce_rates_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, const double *rates, double *out, void *stream)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ || !rates || !out) return fail(ctx, KIDMP_EINVAL, "kidmp_reduce_rates_device: bad argument");
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, rates, "rates")) return rc;
+    if (int rc = check_on_device(ctx, out, "out")) return rc;
+    const int n = KIDMP_NRATES * nz;
+    const size_t need = size_t(RED_CHUNKS) * size_t(n);
+    if (need > ctx->red_elems) {
+        if (ctx->d_red) (void)hipFree(ctx->d_red);
+        ctx->d_red = nullptr; ctx->red_elems = 0;
+        HIPTRY(ctx, hipMalloc((void **)&ctx->d_red, need * sizeof(double)));
+        ctx->red_elems = need;
+    }
+    const int T = 128;
+    hipLaunchKernelGGL(k_reduce_rates_part, dim3((n + T - 1) / T, RED_CHUNKS), dim3(T), 0, (hipStream_t)stream, ncol, n, rates, ctx->d_red);
+    hipLaunchKernelGGL(k_reduce_rates_final, dim3((n + T - 1) / T), dim3(T), 0, (hipStream_t)stream, n, ctx->d_red, out);
+    HIPTRY(ctx, hipGetLastError());
+    return KIDMP_OK;
+}
+
+int kidmp_sanity_device(kidmp_ctx *ctx, int64_t n, const double *qc, const double *qr, const double *nr, const double *qs,
+                        const double *qi, const double *qg, const double *ni, const double *qv, double *out15, void *stream)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (n < 0 || !qc || !qr || !nr || !qs || !qi || !qg || !ni || !qv || !out15) return fail(ctx, KIDMP_EINVAL, "kidmp_sanity_device: bad argument");
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, qc, "qc")) return rc;
+    if (int rc = check_on_device(ctx, out15, "out15")) return rc;
+    if (!ctx->d_sanity) HIPTRY(ctx, hipMalloc((void **)&ctx->d_sanity, 15 * sizeof(unsigned long long)));
+    hipStream_t s = (hipStream_t)stream;
+    HIPTRY(ctx, hipMemsetAsync(ctx->d_sanity, 0, 15 * sizeof(unsigned long long), s));
+    if (n > 0) {
+        SanityPtrs p{{qc, qr, nr, qs, qi, qg, ni, qv}};
+        const int T = 256;
+        int64_t g = (n + T - 1) / T;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(k_sanity, dim3((unsigned)g), dim3(T), 0, s, n, p, ctx->d_sanity);
+    }
+    hipLaunchKernelGGL(k_sanity_final, dim3(1), dim3(64), 0, s, ctx->d_sanity, out15);
+    HIPTRY(ctx, hipGetLastError());
+    return KIDMP_OK;
+}
+
+const char *kidmp_kernel_fingerprint(kidmp_ctx *ctx)
+{
+    if (!ctx || !ctx->ready) return "";
+    DeviceGuard guard_(ctx->cfg.device);
+    ctx->fingerprint = column_kernel_fingerprint(ctx->cfg.iiwarm != 0);
+    return ctx->fingerprint.c_str();
+}
+
 int64_t kidmp_get_table(kidmp_ctx *ctx, const char *name, double *out, int64_t cap)
 {
     if (!ctx || !ctx->ready || !name) return fail(ctx, KIDMP_ESTATE, "kidmp_get_table: bad context");
+    GUARD(ctx);
     for (const Named &e : table_dir(ctx->tables))
         if (!strcmp(e.name, name)) {
             if (!out) return e.n;
@@ -439,6 +607,7 @@ int kidmp_save_table_cache(kidmp_ctx *ctx, const char *dir)
 {
     if (!ctx || !ctx->ready || !dir) return fail(ctx, KIDMP_ESTATE, "kidmp_save_table_cache: bad context");
     if (ctx->hc.iiwarm) return fail(ctx, KIDMP_ESTATE, "kidmp_save_table_cache: iiwarm context has no mixed-phase tables");
+    GUARD(ctx);
     for (CacheFamily &fam : cache_families(ctx->tables)) {
         std::vector<std::vector<double>> host(fam.dev.size(), std::vector<double>(size_t(fam.n)));
         std::vector<const double *> ptr;
@@ -456,6 +625,7 @@ int kidmp_load_table_cache(kidmp_ctx *ctx, const char *dir)
 {
     if (!ctx || !ctx->ready || !dir) return fail(ctx, KIDMP_ESTATE, "kidmp_load_table_cache: bad context");
     if (ctx->hc.iiwarm) return fail(ctx, KIDMP_ESTATE, "kidmp_load_table_cache: iiwarm context has no mixed-phase tables");
+    GUARD(ctx);
     for (CacheFamily &fam : cache_families(ctx->tables)) {
         std::vector<std::vector<double>> host(fam.dev.size(), std::vector<double>(size_t(fam.n)));
         std::vector<double *> ptr;

@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string>
+
 #include "thompson_params.h"
 
 namespace kidmp {
@@ -31,5 +33,6 @@ hipError_t launch_column_step(const StepArgs &a, hipStream_t s);
 hipError_t upload_consts(int slot, const Consts &c);
 bool generated_consts_match(const Consts &c);   // thompson_consts_gen.h vs the run-time host init
 const char *column_kernel_name();
+std::string column_kernel_fingerprint(bool iiwarm);   // source hash + register/LDS/scratch use of the nz <= 120 kernel
 
 }  // namespace kidmp

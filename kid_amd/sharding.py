@@ -29,3 +29,67 @@ def allreduce_precip_sums(sums4, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(sums4, op=dist.ReduceOp.SUM, group=group)
     return sums4
+
+
+class ShardedColumns:
+    """One rank's share of a column batch: the product-side object behind `bench.py --gpus N` and the
+    multi-GPU tests.  Owns a ThompsonMP context bound to this rank's GPU, the shard's state in HBM and its
+    precipitation accumulators; `step` advances the shard (no communication), `diagnostics` reduces the
+    domain diagnostics over all ranks -- the one exchange of the path."""
+
+    def __init__(self, state, rank, world, device, iiwarm, set_Nc=100.0, l_sediment=True, want_rates=False,
+                 local=False):
+        """state: dict of [ncol, nz] float64 arrays (numpy or torch) -- the GLOBAL batch, of which this rank takes its
+        contiguous range; or, with local=True, this rank's own columns (weak-scaling runs generate them per rank)."""
+        import torch
+        from .thompson import NRATES, ThompsonMP
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        n = next(iter(state.values())).shape[0]
+        if local:
+            self.lo, self.hi, self.ncol_global = 0, n, n * self.world
+        else:
+            self.lo, self.hi = shard_bounds(n, rank, world)
+            self.ncol_global = n
+        self.model = ThompsonMP(iiwarm=iiwarm, set_Nc=set_Nc, l_sediment=l_sediment, device=self.device)
+        dev = torch.device("cuda", self.device)
+        self.st = {k: torch.as_tensor(v[self.lo:self.hi]).contiguous().to(dev) for k, v in state.items()}
+        self.ncol, self.nz = self.st["qv"].shape
+        self.ppt = torch.zeros(self.ncol, 4, dtype=torch.float64, device=dev)
+        self.rates = torch.zeros(self.ncol, NRATES, self.nz, dtype=torch.float64, device=dev) if want_rates else None
+
+    def step(self, dt):
+        """One mp_thompson advance of every column of the shard, asynchronous on torch's current stream of the
+        shard's device."""
+        self.model.batch_step(self.st, dt, self.ppt, rates=self.rates)
+
+    def synchronize(self):
+        import torch
+        torch.cuda.synchronize(self.device)
+
+    def diagnostics(self, group=None, cpu_collective=False):
+        """Domain diagnostics over ALL ranks: dict(precip=[4] sums, sanity=[15] (7 maxima, 8 negative counts),
+        rates=[36, nz] sums or None).  RCCL all-reduce on the GPU tensors (SUM, and MAX for the maxima);
+        cpu_collective=True moves them to the host first (gloo rehearsals)."""
+        import torch
+        import torch.distributed as dist
+        precip = self.model.reduce_ppt(self.ppt)
+        sanity = self.model.sanity(self.st)
+        rates = self.model.reduce_rates(self.rates) if self.rates is not None else None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            with torch.cuda.device(self.device):
+                if cpu_collective:
+                    precip, sanity = precip.cpu(), sanity.cpu()
+                    rates = rates.cpu() if rates is not None else None
+                mx, neg = sanity[:7].clone(), sanity[7:].clone()
+                dist.all_reduce(precip, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+                dist.all_reduce(neg, op=dist.ReduceOp.SUM, group=group)
+                if rates is not None:
+                    dist.all_reduce(rates, op=dist.ReduceOp.SUM, group=group)
+                sanity = torch.cat([mx, neg])
+                if not cpu_collective:
+                    torch.cuda.synchronize(self.device)
+        return dict(precip=precip, sanity=sanity, rates=rates)
+
+    def close(self):
+        self.model.close()

@@ -41,8 +41,9 @@ class _Cfg(C.Structure):
 
 
 def lib_path():
-    # KIDMP_LIB: tuning aid only (A/B builds of the same library); the default is the in-tree build
-    return os.environ.get("KIDMP_LIB") or os.path.join(_HERE, "libkidmp.so")
+    """The in-tree build.  No environment override: a profiling or A/B build is selected explicitly with
+    load_library(path) (bench.py --lib) before the first context is made."""
+    return os.path.join(_HERE, "libkidmp.so")
 
 
 _lib = None
@@ -50,12 +51,14 @@ _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
 
-def load_library():
-    """dlopen kid_amd/libkidmp.so and declare the C ABI (include/kidmp.h)."""
+def load_library(path=None):
+    """dlopen kid_amd/libkidmp.so (or an explicitly named build of it) and declare the C ABI (include/kidmp.h)."""
     global _lib
     if _lib is not None:
+        if path is not None and os.path.abspath(path) != _lib._name:
+            raise KidmpError("load_library: %s is already loaded" % _lib._name)
         return _lib
-    path = lib_path()
+    path = os.path.abspath(path) if path else lib_path()
     if not os.path.exists(path):
         raise KidmpError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
@@ -76,6 +79,12 @@ def load_library():
     L.kidmp_default_aerosols_device.argtypes = [_vp, C.c_int64] + [_vp] * 6 + [_vp]
     L.kidmp_reduce_ppt_device.restype = C.c_int
     L.kidmp_reduce_ppt_device.argtypes = [_vp, C.c_int64, _vp, _vp, _vp]
+    L.kidmp_reduce_rates_device.restype = C.c_int
+    L.kidmp_reduce_rates_device.argtypes = [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]
+    L.kidmp_sanity_device.restype = C.c_int
+    L.kidmp_sanity_device.argtypes = [_vp, C.c_int64] + [_vp] * 9 + [_vp]
+    L.kidmp_kernel_fingerprint.restype = C.c_char_p
+    L.kidmp_kernel_fingerprint.argtypes = [_vp]
     L.kidmp_reserve.restype = C.c_int
     L.kidmp_reserve.argtypes = [_vp, C.c_int64, C.c_int32]
     L.kidmp_math_probe.restype = C.c_int
@@ -166,6 +175,13 @@ class ThompsonMP:
             _np_ptr(ppt), _np_ptr(rates) if want_rates else None))
         return ppt, rates
 
+    def _want(self, a, dtype, shape, what):
+        """A device-entry argument: contiguous CUDA tensor of the given dtype/shape on THIS context's GPU."""
+        if not (a.is_cuda and a.dtype == dtype and a.is_contiguous() and tuple(a.shape) == tuple(shape)):
+            raise KidmpError("%s must be a contiguous %s CUDA tensor %s" % (what, str(dtype).replace("torch.", ""), list(shape)))
+        if a.device.index != self.device:
+            raise KidmpError("%s lives on cuda:%d but this context is bound to cuda:%d" % (what, a.device.index, self.device))
+
     # ---- batched device entry: torch CUDA tensors [ncol, nz], in place ----
     def batch_step(self, st, dt, ppt, rates=None, nstep=None, stream=None):
         """st: dict of float64 CUDA tensors [ncol, nz] (STATE_NAMES + p, dz; w optional).
@@ -174,20 +190,17 @@ class ThompsonMP:
         import torch
         q = st["qv"]
         ncol, nz = q.shape
-        for k in STATE_NAMES + ("p", "dz"):
-            a = st[k]
-            if not (a.is_cuda and a.dtype == torch.float64 and a.is_contiguous() and tuple(a.shape) == (ncol, nz)):
-                raise KidmpError("batch_step: %s must be a contiguous float64 CUDA tensor [ncol, nz]" % k)
-        if not (ppt.is_cuda and ppt.dtype == torch.float64 and ppt.is_contiguous() and tuple(ppt.shape) == (ncol, 4)):
-            raise KidmpError("batch_step: ppt must be float64 CUDA [ncol, 4]")
-        if rates is not None and not (rates.is_cuda and rates.dtype == torch.float64 and rates.is_contiguous()
-                                      and tuple(rates.shape) == (ncol, NRATES, nz)):
-            raise KidmpError("batch_step: rates must be float64 CUDA [ncol, 36, nz]")
-        if nstep is not None and not (nstep.is_cuda and nstep.dtype == torch.int32 and nstep.is_contiguous()
-                                      and tuple(nstep.shape) == (ncol, 4)):
-            raise KidmpError("batch_step: nstep must be int32 CUDA [ncol, 4]")
-        s = stream if stream is not None else torch.cuda.current_stream(q.device).cuda_stream
         w = st.get("w")
+        for k in STATE_NAMES + ("p", "dz"):
+            self._want(st[k], torch.float64, (ncol, nz), "batch_step: " + k)
+        if w is not None:
+            self._want(w, torch.float64, (ncol, nz), "batch_step: w")
+        self._want(ppt, torch.float64, (ncol, 4), "batch_step: ppt")
+        if rates is not None:
+            self._want(rates, torch.float64, (ncol, NRATES, nz), "batch_step: rates")
+        if nstep is not None:
+            self._want(nstep, torch.int32, (ncol, 4), "batch_step: nstep")
+        s = stream if stream is not None else torch.cuda.current_stream(q.device).cuda_stream
         args = [st[k].data_ptr() for k in STATE_NAMES] + [st["p"].data_ptr(), w.data_ptr() if w is not None else None,
                                                           st["dz"].data_ptr(), ppt.data_ptr(),
                                                           rates.data_ptr() if rates is not None else None,
@@ -197,6 +210,8 @@ class ThompsonMP:
     def default_aerosols(self, qv, t, p, stream=None):
         """nc, nwfa, nifa for the inputs the KiD wrapper leaves unset (W:36; formulas M:958-964)."""
         import torch
+        for name, a in (("qv", qv), ("t", t), ("p", p)):
+            self._want(a, torch.float64, tuple(qv.shape), "default_aerosols: " + name)
         nc, nwfa, nifa = torch.empty_like(qv), torch.empty_like(qv), torch.empty_like(qv)
         s = stream if stream is not None else torch.cuda.current_stream(qv.device).cuda_stream
         self._check(load_library().kidmp_default_aerosols_device(
@@ -211,10 +226,42 @@ class ThompsonMP:
     def reduce_ppt(self, ppt, stream=None):
         """Domain sums of the surface precipitation on the device (W:248-275 analogue)."""
         import torch
+        self._want(ppt, torch.float64, (ppt.shape[0], 4), "reduce_ppt: ppt")
         out = torch.empty(4, dtype=torch.float64, device=ppt.device)
         s = stream if stream is not None else torch.cuda.current_stream(ppt.device).cuda_stream
         self._check(load_library().kidmp_reduce_ppt_device(self._h, ppt.shape[0], ppt.data_ptr(), out.data_ptr(), s))
         return out
+
+    def reduce_rates(self, rates, stream=None):
+        """Sum over columns of the rate diagnostics: [ncol, 36, nz] -> [36, nz] (the nx-mean profiles KiD plots are
+        this / ncol).  Fixed summation order."""
+        import torch
+        ncol, nr, nz = rates.shape
+        self._want(rates, torch.float64, (ncol, NRATES, nz), "reduce_rates: rates")
+        out = torch.empty(NRATES, nz, dtype=torch.float64, device=rates.device)
+        s = stream if stream is not None else torch.cuda.current_stream(rates.device).cuda_stream
+        self._check(load_library().kidmp_reduce_rates_device(self._h, ncol, nz, rates.data_ptr(), out.data_ptr(), s))
+        return out
+
+    SANITY_MAX = ("qc", "qr", "nr", "qs", "qi", "qg", "ni")
+    SANITY_NEG = ("qc", "qr", "nr", "qs", "qi", "qg", "ni", "qv")
+
+    def sanity(self, st, stream=None):
+        """The post-step scan of the scheme's 3-D driver (M:1025-1094): [15] float64 on the device =
+        maxima of SANITY_MAX, then counts of negative entries of SANITY_NEG."""
+        import torch
+        q = st["qv"]
+        for k in self.SANITY_NEG:
+            self._want(st[k], torch.float64, tuple(q.shape), "sanity: " + k)
+        out = torch.empty(15, dtype=torch.float64, device=q.device)
+        s = stream if stream is not None else torch.cuda.current_stream(q.device).cuda_stream
+        self._check(load_library().kidmp_sanity_device(self._h, q.numel(), *[st[k].data_ptr() for k in self.SANITY_NEG],
+                                                       out.data_ptr(), s))
+        return out
+
+    def kernel_fingerprint(self):
+        """'src:<hash>;vgpr:<n>;lds:<bytes>;scratch:<bytes>' of this context's nz <= 120 column-step kernel."""
+        return load_library().kidmp_kernel_fingerprint(self._h).decode()
 
     # ---- introspection for parity tests ----
     MATH_FUNCS = ("log", "log10", "exp", "exp10", "sqrt", "cbrt", "pow")

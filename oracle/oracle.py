@@ -56,6 +56,9 @@ def lib():
         L.th_oracle_batch_ex.restype = C.c_int
         L.th_oracle_batch_ex.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_double] + [_dp] * 16 + [
             C.c_int, C.POINTER(C.c_int)]
+        L.th_oracle_batch_force.restype = C.c_int
+        L.th_oracle_batch_force.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_double] + [_dp] * 16 + [
+            C.c_int, C.POINTER(C.c_int), C.c_int]
         L.th_oracle_default_aerosols.argtypes = [C.c_void_p, C.c_int] + [_dp] * 6
         L.th_oracle_kid_interface.restype = C.c_int
         L.th_oracle_kid_interface.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double,
@@ -123,17 +126,18 @@ class Oracle:
         return ppt, rates, list(nstep), bool(rc)
 
     # -- batch, k-fastest [ncol, nz] ----------------------------------
-    def batch_step(self, st, dt, nthreads=None, want_illcond=False):
+    def batch_step(self, st, dt, nthreads=None, want_illcond=False, force=0):
         """In-place step of [ncol, nz] arrays; returns ppt [ncol, 4] (and, if asked, the int32
-        [ncol, nz] ill-conditioning flags of th_oracle_mp_thompson_ex)."""
+        [ncol, nz] ill-conditioning flags of th_oracle_mp_thompson_ex).  force = 1 / 2 takes the
+        residue-decided tests of block Q (M:3587, M:3596) as true / false at the flagged levels."""
         ncol, nz = st["qv"].shape
         for k in STATE + FORCING:
             assert st[k].dtype == np.float64 and st[k].flags.c_contiguous and st[k].shape == (ncol, nz), k
         ppt = np.zeros((ncol, 4))
         flags = np.zeros((ncol, nz), dtype=np.int32) if want_illcond else None
-        lib().th_oracle_batch_ex(self._h, ncol, nz, float(dt), *[_p(st[k]) for k in STATE],
-                                 *[_p(st[k]) for k in FORCING], _p(ppt), nthreads or self.nthreads,
-                                 flags.ctypes.data_as(C.POINTER(C.c_int)) if want_illcond else None)
+        lib().th_oracle_batch_force(self._h, ncol, nz, float(dt), *[_p(st[k]) for k in STATE],
+                                    *[_p(st[k]) for k in FORCING], _p(ppt), nthreads or self.nthreads,
+                                    flags.ctypes.data_as(C.POINTER(C.c_int)) if want_illcond else None, int(force))
         return (ppt, flags) if want_illcond else ppt
 
     def default_aerosols(self, qv, t, p):

@@ -63,7 +63,7 @@ int th_oracle_mp_thompson(const th_oracle *o,
  * cancellation residue (bit 0: `xri > 0.` at M:3587, bit 1: `xrc > 0.` at
  * M:3596 after the species was removed completely).  At such levels the
  * reference's own output is chaotic (a 1-ulp change upstream flips it), so
- * parity tests exclude them (tests/parity.py). */
+ * parity tests compare them against both outcomes (th_oracle_mp_thompson_force). */
 int th_oracle_mp_thompson_ex(const th_oracle *o,
                              double *qv1d, double *qc1d, double *qi1d,
                              double *qr1d, double *qs1d, double *qg1d,
@@ -73,6 +73,20 @@ int th_oracle_mp_thompson_ex(const th_oracle *o,
                              const double *dzq, double ppt[4],
                              int nz, double dt, double *rates, int *nstep_out,
                              int *illcond);
+
+/* Same, with the two residue-decided tests of block Q forced (oracle only; 0 = the reference's own decision,
+ * 1 = taken, 2 = not taken, applied only at the levels th_oracle_mp_thompson_ex flags): the two outcomes an
+ * implementation with different rounding may legitimately produce there.  Parity tests require every flagged
+ * level of the HIP result to equal one of them (tests/parity.py). */
+int th_oracle_mp_thompson_force(const th_oracle *o,
+                                double *qv1d, double *qc1d, double *qi1d,
+                                double *qr1d, double *qs1d, double *qg1d,
+                                double *ni1d, double *nr1d, double *nc1d,
+                                double *nwfa1d, double *nifa1d, double *t1d,
+                                const double *p1d, const double *w1d,
+                                const double *dzq, double ppt[4],
+                                int nz, double dt, double *rates, int *nstep_out,
+                                int *illcond, int force);
 
 /* Batch of columns, k-fastest layout x[col*nz + k]; ppt[col*4 + s].
  * Runs th_oracle_mp_thompson per column on nthreads host threads
@@ -90,6 +104,13 @@ int th_oracle_batch_ex(const th_oracle *o, long ncol, int nz, double dt,
                        double *nc, double *nwfa, double *nifa, double *t,
                        const double *p, const double *w, const double *dz,
                        double *ppt, int nthreads, int *illcond /* [ncol*nz] or NULL */);
+
+int th_oracle_batch_force(const th_oracle *o, long ncol, int nz, double dt,
+                          double *qv, double *qc, double *qi, double *qr,
+                          double *qs, double *qg, double *ni, double *nr,
+                          double *nc, double *nwfa, double *nifa, double *t,
+                          const double *p, const double *w, const double *dz,
+                          double *ppt, int nthreads, int *illcond /* [ncol*nz] or NULL */, int force);
 
 /* Non-aerosol defaults for the inputs the KiD wrapper leaves unset
  * (decision U2 of SURVEY 8c; formulas of M:958-964). */

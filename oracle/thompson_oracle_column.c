@@ -112,8 +112,8 @@ int th_oracle_mp_thompson(const th_oracle *o,
                           const double *dzq, double ppt[4],
                           int nz, double dt, double *rates, int *nstep_out)
 {
-    return th_oracle_mp_thompson_ex(o, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d,
-                                    t1d, p1d, w1d, dzq, ppt, nz, dt, rates, nstep_out, NULL);
+    return th_oracle_mp_thompson_force(o, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d,
+                                       t1d, p1d, w1d, dzq, ppt, nz, dt, rates, nstep_out, NULL, 0);
 }
 
 int th_oracle_mp_thompson_ex(const th_oracle *o,
@@ -124,6 +124,19 @@ int th_oracle_mp_thompson_ex(const th_oracle *o,
                              const double *p1d, const double *w1d,
                              const double *dzq, double ppt[4],
                              int nz, double dt, double *rates, int *nstep_out, int *illcond)
+{
+    return th_oracle_mp_thompson_force(o, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d,
+                                       t1d, p1d, w1d, dzq, ppt, nz, dt, rates, nstep_out, illcond, 0);
+}
+
+int th_oracle_mp_thompson_force(const th_oracle *o,
+                                double *qv1d, double *qc1d, double *qi1d,
+                                double *qr1d, double *qs1d, double *qg1d,
+                                double *ni1d, double *nr1d, double *nc1d,
+                                double *nwfa1d, double *nifa1d, double *t1d,
+                                const double *p1d, const double *w1d,
+                                const double *dzq, double ppt[4],
+                                int nz, double dt, double *rates, int *nstep_out, int *illcond, int force)
 {
     (void)w1d;   /* only read by activ_ncloud (aerosol-aware, M:2797) */
     const int kts = 0, kte = nz - 1;
@@ -1470,15 +1483,23 @@ int th_oracle_mp_thompson_ex(const th_oracle *o,
     if (!iiwarm) {
         for (k = kts; k <= kte; k++) {
             xri = MAXD(0.0, qi1d[k] + qiten[k] * DT);
-            if (illcond) {
-                /* conditioning diagnostics (oracle only): the two `> 0.0` tests of this block are
-                 * taken on cancellation residues when the species was removed completely */
+            /* conditioning diagnostics (oracle only): the two `> 0.0` tests of this block are
+             * taken on cancellation residues when the species was removed completely.  `force`
+             * (oracle only, 0 = the reference's own decision) takes such a test as true (1) or
+             * false (2): the two outcomes an implementation with other rounding may legitimately
+             * produce at that level; block Q and block R are pointwise in k, so nothing else moves. */
+            int res_ri = 0, res_rc = 0;
+            {
                 double sc = MAXD(fabs(qi1d[k]), fabs(qiten[k] * DT));
-                if (temp[k] > T_0 && sc > 0. && fabs(qi1d[k] + qiten[k] * DT) <= 1e-9 * sc) illcond[k] |= 1;
+                if (temp[k] > T_0 && sc > 0. && fabs(qi1d[k] + qiten[k] * DT) <= 1e-9 * sc) res_ri = 1;
                 sc = MAXD(fabs(qc1d[k]), fabs(qcten[k] * DT));
-                if (temp[k] < HGFR && sc > 0. && fabs(qc1d[k] + qcten[k] * DT) <= 1e-9 * sc) illcond[k] |= 2;
+                /* xrc is re-evaluated after the melt branch; T > T_0 and T < HGFR exclude each other, so qcten
+                 * is still the value this test will see */
+                if (temp[k] < HGFR && sc > 0. && fabs(qc1d[k] + qcten[k] * DT) <= 1e-9 * sc) res_rc = 1;
+                if (illcond) illcond[k] |= res_ri | (res_rc << 1);
             }
-            if ((temp[k] > T_0) && (xri > 0.0)) {
+            const int take_ri = (force && res_ri) ? (force == 1) : (xri > 0.0);
+            if ((temp[k] > T_0) && take_ri) {
                 qcten[k] = qcten[k] + xri * odt;
                 ncten[k] = ncten[k] + ni1d[k] * odt;
                 qiten[k] = qiten[k] - xri * odt;
@@ -1487,7 +1508,8 @@ int th_oracle_mp_thompson_ex(const th_oracle *o,
             }
 
             xrc = MAXD(0.0, qc1d[k] + qcten[k] * DT);
-            if ((temp[k] < HGFR) && (xrc > 0.0)) {
+            const int take_rc = (force && res_rc) ? (force == 1) : (xrc > 0.0);
+            if ((temp[k] < HGFR) && take_rc) {
                 lfus2 = lsub - lvap[k];
                 xnc = nc1d[k] + ncten[k] * DT;
                 qiten[k] = qiten[k] + xrc * odt;
@@ -1581,7 +1603,7 @@ void th_oracle_default_aerosols(const th_oracle *o, int nz,
 typedef struct {
     const th_oracle *o; long c0, c1; int nz; double dt;
     double *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;
-    const double *p, *w, *dz; double *ppt; int *illcond;
+    const double *p, *w, *dz; double *ppt; int *illcond; int force;
 } batch_job;
 
 static void *batch_worker(void *arg)
@@ -1590,11 +1612,11 @@ static void *batch_worker(void *arg)
     const size_t nz = (size_t)b->nz;
     for (long c = b->c0; c < b->c1; c++) {
         size_t off = (size_t)c * nz;
-        th_oracle_mp_thompson_ex(b->o, b->qv + off, b->qc + off, b->qi + off, b->qr + off,
+        th_oracle_mp_thompson_force(b->o, b->qv + off, b->qc + off, b->qi + off, b->qr + off,
                                  b->qs + off, b->qg + off, b->ni + off, b->nr + off,
                                  b->nc + off, b->nwfa + off, b->nifa + off, b->t + off,
                                  b->p + off, b->w + off, b->dz + off, b->ppt + 4 * (size_t)c,
-                                 b->nz, b->dt, NULL, NULL, b->illcond ? b->illcond + off : NULL);
+                                 b->nz, b->dt, NULL, NULL, b->illcond ? b->illcond + off : NULL, b->force);
     }
     return NULL;
 }
@@ -1617,13 +1639,24 @@ int th_oracle_batch_ex(const th_oracle *o, long ncol, int nz, double dt,
                        const double *p, const double *w, const double *dz,
                        double *ppt, int nthreads, int *illcond)
 {
+    return th_oracle_batch_force(o, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt,
+                                 nthreads, illcond, 0);
+}
+
+int th_oracle_batch_force(const th_oracle *o, long ncol, int nz, double dt,
+                          double *qv, double *qc, double *qi, double *qr,
+                          double *qs, double *qg, double *ni, double *nr,
+                          double *nc, double *nwfa, double *nifa, double *t,
+                          const double *p, const double *w, const double *dz,
+                          double *ppt, int nthreads, int *illcond, int force)
+{
     if (nthreads < 1) nthreads = 1;
     if (nthreads > ncol) nthreads = (int)(ncol > 0 ? ncol : 1);
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
     batch_job *jb = (batch_job *)malloc(sizeof(batch_job) * nthreads);
     for (int i = 0; i < nthreads; i++) {
         batch_job b = { o, ncol * i / nthreads, ncol * (i + 1) / nthreads, nz, dt,
-                        qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt, illcond };
+                        qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt, illcond, force };
         jb[i] = b;
         if (nthreads == 1) batch_worker(&jb[i]);
         else pthread_create(&th[i], NULL, batch_worker, &jb[i]);

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import cases
-from parity import OUT, TOL, conditioned_mask, max_rel
+from parity import OUT, TOL, assert_parity, max_rel
 
 pytestmark = pytest.mark.gpu
 R1 = 1e-12
@@ -39,29 +39,13 @@ def _check_invariants(dev, ppt):
 
 # Random samples of a large batch reach into the tail of the error distribution: where the saturation
 # adjustment (M:2780-2790) condenses 1e-7..1e-6 kg/kg out of 2e-2 kg/kg of vapour, a one-ulp difference in the
-# updated temperature moves the new cloud water by several 1e-10 (tools/parity_stats.py: 99.97 % of 20 000
-# config-5 columns are within 1e-10, the worst level is 4e-10).  So: every level < TOL_TAIL, >= 99 % of the
-# sampled columns < TOL.  The curated cases of test_gpu_parity.py keep the plain 1e-10 bound.
-TOL_TAIL = 2e-9
-
-
+# updated temperature moves the new cloud water by several 1e-10 -- and the ORACLE's own output moves by as much
+# under a 2-ulp input perturbation there (profiles/r02_parity_tail.jsonl shows both side by side).  So: every level
+# within max(1e-10, 10 x the oracle's measured sensitivity at that level), nothing excluded.
 def _spot_check(oracle, st0, dev, ppt, idx):
     s = {k: np.ascontiguousarray(v[idx].copy()) for k, v in st0.items()}
-    ref = {k: v.copy() for k, v in s.items()}
-    rppt = oracle.batch_step(ref, 10.0)
-    mask = conditioned_mask(oracle, s, 10.0, ref)
     got = {k: dev[k][idx].cpu().numpy() for k in OUT}
-    mx, per = max_rel(got, ref, OUT, mask)
-    assert mx < TOL_TAIL, per
-    from parity import FLOORS
-    worst = np.zeros(len(idx))
-    for k in OUT:
-        e = np.where(mask, np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), FLOORS[k]), 0.0)
-        worst = np.maximum(worst, e.max(axis=1))
-    assert (worst < TOL).mean() >= 0.99, float((worst < TOL).mean())
-    g = ppt[idx].cpu().numpy()
-    assert float(np.max(np.abs(g - rppt) / np.maximum(np.abs(rppt), 1e-12))) < TOL
-    return mask
+    return assert_parity(oracle, s, 10.0, got, ppt[idx].cpu().numpy(), tol=TOL)
 
 
 def test_config2_full_size_replicas(gpu_warm, oracle_warm):

@@ -1,8 +1,13 @@
 """Multi-rank path on CPU: world_size-2 gloo.  Columns shard with no data-path collective;
-the only exchange is the all-reduce of the 4 precipitation sums.  The stepper here is the
-oracle (allowed in tests); on GPUs the same sharding code feeds ThompsonMP.batch_step."""
+the only exchange is the all-reduce of the domain diagnostics.  Without a GPU the stepper of the
+first test is the oracle (allowed in tests) and the second test drives bench.py's own launcher in its
+rehearsal mode (no physics); on the GPU box tests/test_gpu_sharding.py runs the same launcher and
+kid_amd.sharding.ShardedColumns on the HIP path."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch.multiprocessing as mp
@@ -65,3 +70,30 @@ def test_two_rank_run_equals_single_rank(tmp_path, oracle_warm):
         assert np.array_equal(np.concatenate([p[k] for p in parts]), st[k]), k     # concatenation equality
     for p in parts:
         np.testing.assert_allclose(p["sums"], tot, rtol=1e-13)                     # all-reduced diagnostics
+
+
+def test_bench_launcher_spawns_ranks_and_reduces():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent must start two fresh rank processes with
+    RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set, they must rendezvous on 127.0.0.1 and all-reduce, and rank 0 must
+    print ONE line with n_gpus = 2.  CPU box: --rehearse-launcher (no physics, value 0)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--rehearse-launcher", "--steps", "4", "--warmup", "1", "--ncol", "10"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] == 0.0 and "no physics" in d["data"]
+    # rank r adds 1e-3*dt*(r+1) per column and step (5 steps incl. warm-up): the reduced sum proves both ranks ran
+    np.testing.assert_allclose(d["precip_domain_sums"][0], 10 * 5 * 1e-3 * 10.0 * (1 + 2), rtol=1e-12)
+
+
+def test_bench_refuses_to_fake_a_gpu_run():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU fallback" in (r.stderr + r.stdout)
