@@ -83,6 +83,17 @@ int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
                           const double *p, const double *w, const double *dz,
                           double *ppt, double *rates);
 
+/* Same, also returning the substep counts: nstep (may be NULL) receives [ncol][4] int32 (rain, ice, snow,
+ * graupel; M:3365,3447,3504,3553).  All four are 0 for a column that left through the `no_micro` early return
+ * (M:1540) -- such a column makes no save_dg call in the reference, which is how the Fortran drop-in knows to
+ * skip it when it replays the rate diagnostics. */
+int kidmp_batch_step_host_diag(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
+                               double *qv, double *qc, double *qi, double *qr,
+                               double *qs, double *qg, double *ni, double *nr,
+                               double *nc, double *nwfa, double *nifa, double *t,
+                               const double *p, const double *w, const double *dz,
+                               double *ppt, double *rates, int32_t *nstep);
+
 /* Same, on DEVICE pointers (state resident in HBM), enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = the null stream).  Asynchronous.
  * nstep (may be NULL) receives [ncol][4] int32 substep counts (rain, ice,

@@ -416,6 +416,16 @@ int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
                           double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
                           const double *p, const double *w, const double *dz, double *ppt, double *rates)
 {
+    return kidmp_batch_step_host_diag(ctx, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz,
+                                      ppt, rates, nullptr);
+}
+
+int kidmp_batch_step_host_diag(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
+                               double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
+                               double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
+                               const double *p, const double *w, const double *dz, double *ppt, double *rates,
+                               int32_t *nstep)
+{
     double *io[12] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t};
     const double *in[2] = {p, dz};
     const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
@@ -423,7 +433,8 @@ int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     if (ncol == 0) return KIDMP_OK;
     GUARD(ctx);
     const size_t prof = size_t(ncol) * size_t(nz);
-    const size_t need = (14 * prof + 4 * size_t(ncol) + (rates ? size_t(KIDMP_NRATES) * prof : 0)) * sizeof(double);
+    const size_t need = (14 * prof + 4 * size_t(ncol) + (rates ? size_t(KIDMP_NRATES) * prof : 0)
+                         + (nstep ? (4 * size_t(ncol) + 1) / 2 : 0)) * sizeof(double);
     if (need > ctx->stage_bytes) {
         if (ctx->d_stage) (void)hipFree(ctx->d_stage);
         ctx->d_stage = nullptr;
@@ -437,16 +448,19 @@ int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     for (int i = 0; i < 2; ++i) { din[i] = d; d += prof; }
     double *dppt = d; d += 4 * size_t(ncol);
     double *drates = rates ? d : nullptr;
+    if (rates) d += size_t(KIDMP_NRATES) * prof;
+    int32_t *dnstep = nstep ? reinterpret_cast<int32_t *>(d) : nullptr;
     hipStream_t s = ctx->stream;
     for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(dio[i], io[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
     for (int i = 0; i < 2; ++i) HIPTRY(ctx, hipMemcpyAsync(din[i], in[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
     HIPTRY(ctx, hipMemcpyAsync(dppt, ppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyHostToDevice, s));
     int rc = kidmp_batch_step_device(ctx, ncol, nz, dt, dio[0], dio[1], dio[2], dio[3], dio[4], dio[5], dio[6], dio[7],
-                                     dio[8], dio[9], dio[10], dio[11], din[0], w, din[1], dppt, drates, nullptr, s);
+                                     dio[8], dio[9], dio[10], dio[11], din[0], w, din[1], dppt, drates, dnstep, s);
     if (rc) return rc;
     for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(io[i], dio[i], prof * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPTRY(ctx, hipMemcpyAsync(ppt, dppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyDeviceToHost, s));
     if (rates) HIPTRY(ctx, hipMemcpyAsync(rates, drates, size_t(KIDMP_NRATES) * prof * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (nstep) HIPTRY(ctx, hipMemcpyAsync(nstep, dnstep, 4 * size_t(ncol) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIPTRY(ctx, hipStreamSynchronize(s));
     return KIDMP_OK;
 }

@@ -16,19 +16,38 @@
 ! compiled with 4-byte or 8-byte default REAL (the computation is fp64).
 !
 ! Like the reference it takes its switches from KiD's own modules:
-! iiwarm, set_Nc (namelists, M:22) and l_sediment (switches, M:20).
+! iiwarm, set_Nc (namelists, M:22), l_sediment (switches, M:20) and nx (parameters, M:23).
+!
+! Side effects kept: the 36 process-rate diagnostics the reference emits from inside mp_thompson
+! (M:2962-3124) are replayed after the batched call through KiD's own save_dg, same names, same
+! order (per column, per level: 30 mixed-phase rates unless iiwarm, then 6 warm ones), same
+! nx == 1 / nx > 1 call forms, and none for a column that took the no_micro early return
+! (M:1540).  l_rate_diagnostics = .false. switches them off (big batches: the rate buffer is
+! 36 profiles per column).  kidmp_device (or the environment variable KIDMP_DEVICE) selects the GPU.
 !
 module module_mp_thompson09n
 
   use iso_c_binding
   use switches, only: l_sediment
   use namelists, only: iiwarm, set_Nc
+  use parameters, only: nx
+  use diagnostics, only: save_dg, i_dgtime
 
   implicit none
   private
 
   public :: thompson_init, mp_thompson, mp_thompson_batch, thompson_finalize
   logical, public :: is_aerosol_aware = .false.          ! M:28 (only .false. is supported)
+  logical, public :: l_rate_diagnostics = .true.         ! replay the save_dg calls of M:2962-3124
+  integer, public :: kidmp_device = 0                    ! HIP device ordinal of this process (one process per GPU)
+
+  ! the diagnosed rates in the reference's emission order (M:2967-3119): 30 mixed-phase, then 6 warm
+  integer, parameter :: NRATES = 36, NRATES_MIXED = 30
+  character(7), parameter :: rate_names(NRATES) = (/ &
+       'pri_inu', 'pri_ide', 'prs_ide', 'prs_sde', 'prg_gde', 'pri_wfz', 'prs_scw', 'prg_scw', 'prg_gcw', 'pri_ihm', &
+       'pri_rfz', 'prs_iau', 'prs_sci', 'pri_rci', 'pni_inu', 'pni_ihm', 'pni_wfz', 'pni_rfz', 'pni_ide', 'pni_iau', &
+       'pni_sci', 'pni_rci', 'prr_sml', 'prr_gml', 'pnr_rcs', 'pnr_rcg', 'pnr_rci', 'pnr_sml', 'pnr_gml', 'pnr_rfz', &
+       'prr_wau', 'prr_rcw', 'prv_rev', 'pnr_wau', 'pnr_rev', 'pnr_rcr' /)
 
   type, bind(C) :: kidmp_cfg
      integer(c_int32_t) :: iiwarm
@@ -55,8 +74,8 @@ module module_mp_thompson09n
        type(c_ptr), value :: ctx
        type(c_ptr) :: msg
      end function kidmp_last_error
-     integer(c_int) function kidmp_batch_step_host(ctx, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, &
-          nc, nwfa, nifa, t, p, w, dz, ppt, rates) bind(C, name='kidmp_batch_step_host')
+     integer(c_int) function kidmp_batch_step_host_diag(ctx, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, &
+          nc, nwfa, nifa, t, p, w, dz, ppt, rates, nstep) bind(C, name='kidmp_batch_step_host_diag')
        import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
        type(c_ptr), value :: ctx
        integer(c_int64_t), value :: ncol
@@ -65,8 +84,8 @@ module module_mp_thompson09n
        real(c_double), intent(inout) :: qv(*), qc(*), qi(*), qr(*), qs(*), qg(*), ni(*), nr(*), &
             nc(*), nwfa(*), nifa(*), t(*), ppt(*)
        real(c_double), intent(in) :: p(*), w(*), dz(*)
-       type(c_ptr), value :: rates
-     end function kidmp_batch_step_host
+       type(c_ptr), value :: rates, nstep            ! NULL, or [ncol][36][nz] doubles / [ncol][4] int32
+     end function kidmp_batch_step_host_diag
   end interface
 
 contains
@@ -95,6 +114,8 @@ contains
   subroutine thompson_init
     type(kidmp_cfg) :: cfg
     integer(c_int) :: rc
+    character(16) :: envdev
+    integer :: envstat
     if (c_associated(ctx)) return                         ! micro_init guard, M:384-389
     if (is_aerosol_aware) then
        write(*,*) 'module_mp_thompson09n: is_aerosol_aware=.true. is not supported by the MI355X build'
@@ -103,7 +124,9 @@ contains
     cfg%iiwarm = merge(1_c_int32_t, 0_c_int32_t, iiwarm)
     cfg%l_sediment = merge(1_c_int32_t, 0_c_int32_t, l_sediment)
     cfg%set_Nc = real(set_Nc, c_double)
-    cfg%device = 0
+    call get_environment_variable('KIDMP_DEVICE', envdev, status=envstat)
+    if (envstat == 0 .and. len_trim(envdev) > 0) read(envdev, *, iostat=envstat) kidmp_device
+    cfg%device = int(kidmp_device, c_int32_t)
     cfg%reserved = 0
     rc = kidmp_init(cfg, ctx)
     call stop_on_error(rc, 'thompson_init')
@@ -143,19 +166,47 @@ contains
     real, dimension(nz,ncol), intent(inout) :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t
     real, dimension(nz,ncol), intent(in) :: p, w, dz
     real, dimension(4,ncol), intent(inout) :: ppt
-    real(c_double), allocatable :: s(:,:,:), f(:,:,:), pp(:,:)
+    real(c_double), allocatable, target :: s(:,:,:), f(:,:,:), pp(:,:), rates(:,:,:)
+    integer(c_int32_t), allocatable, target :: nstep(:,:)
+    type(c_ptr) :: prates, pnstep
     integer(c_int) :: rc
+    integer :: i, k, r, r0
     if (.not. c_associated(ctx)) call thompson_init
     allocate(s(nz,ncol,12), f(nz,ncol,3), pp(4,ncol))
+    prates = c_null_ptr;  pnstep = c_null_ptr
+    if (l_rate_diagnostics) then
+       allocate(rates(nz,NRATES,ncol), nstep(4,ncol))       ! the C ABI's [ncol][36][nz] / [ncol][4]
+       prates = c_loc(rates);  pnstep = c_loc(nstep)
+    end if
     s(:,:,1) = qv;  s(:,:,2) = qc;  s(:,:,3) = qi;   s(:,:,4) = qr
     s(:,:,5) = qs;  s(:,:,6) = qg;  s(:,:,7) = ni;   s(:,:,8) = nr
     s(:,:,9) = nc;  s(:,:,10) = nwfa; s(:,:,11) = nifa; s(:,:,12) = t
     f(:,:,1) = p;   f(:,:,2) = w;   f(:,:,3) = dz
     pp = ppt
-    rc = kidmp_batch_step_host(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_double), &
+    rc = kidmp_batch_step_host_diag(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_double), &
          s(:,:,1), s(:,:,2), s(:,:,3), s(:,:,4), s(:,:,5), s(:,:,6), s(:,:,7), s(:,:,8), &
-         s(:,:,9), s(:,:,10), s(:,:,11), s(:,:,12), f(:,:,1), f(:,:,2), f(:,:,3), pp, c_null_ptr)
+         s(:,:,9), s(:,:,10), s(:,:,11), s(:,:,12), f(:,:,1), f(:,:,2), f(:,:,3), pp, prates, pnstep)
     call stop_on_error(rc, 'mp_thompson')
+    ! ---- the KiD block of M:2962-3124: per column, per level, 30 mixed-phase rates (.not. iiwarm) then 6 warm
+    !      ones; save_dg(k, value, ...) when nx == 1, save_dg(k, ii, value, ...) otherwise; a column that left
+    !      through the no_micro return (M:1540: all four substep counts 0) never reached the block ----
+    if (l_rate_diagnostics) then
+       r0 = 1
+       if (iiwarm) r0 = NRATES_MIXED + 1
+       do i = 1, ncol
+          if (all(nstep(:,i) == 0)) cycle
+          do k = 1, nz
+             do r = r0, NRATES
+                if (nx == 1) then
+                   call save_dg(k, rates(k,r,i), rate_names(r), i_dgtime, units='/kg/s', dim='z')
+                else
+                   call save_dg(k, i, rates(k,r,i), rate_names(r), i_dgtime, units='/kg/s', dim='z')
+                end if
+             end do
+          end do
+       end do
+       deallocate(rates, nstep)
+    end if
     qv = s(:,:,1);  qc = s(:,:,2);  qi = s(:,:,3);   qr = s(:,:,4)
     qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7);   nr = s(:,:,8)
     nc = s(:,:,9);  nwfa = s(:,:,10); nifa = s(:,:,11); t = s(:,:,12)

@@ -29,27 +29,71 @@ module physconst
 end module physconst
 
 module diagnostics
+  ! Records every save_dg call (form, name, indices, value) so that the tests can assert names, order and
+  ! values of what the drop-in modules emit; KiD's real module writes them to netCDF.
   integer :: i_dgtime = 1
-  real :: last_scalar(8) = 0.
-  integer :: n_scalar = 0
+  integer, parameter :: maxlog = 200000
+  integer :: nlog = 0
+  logical :: recording = .false.
+  character(40) :: log_name(maxlog)
+  character(8) :: log_form(maxlog), log_units(maxlog), log_dim(maxlog)
+  integer :: log_k(maxlog), log_i(maxlog)
+  double precision :: log_v(maxlog)
   interface save_dg
-     module procedure save_dg_scalar, save_dg_1d
+     module procedure save_dg_scalar, save_dg_1d, save_dg_k_dp, save_dg_ki_dp
   end interface
 contains
-  subroutine save_dg_scalar(v, name, it, units, dim)
+  subroutine put(form, name, k, i, v, units, dim)
+    character(*), intent(in) :: form, name, units, dim
+    integer, intent(in) :: k, i
+    double precision, intent(in) :: v
+    if (.not. recording) return
+    if (nlog >= maxlog) stop 'diagnostics stub: log full'
+    nlog = nlog + 1
+    log_form(nlog) = form;  log_name(nlog) = name;  log_k(nlog) = k;  log_i(nlog) = i;  log_v(nlog) = v
+    log_units(nlog) = units; log_dim(nlog) = dim
+  end subroutine put
+  subroutine save_dg_scalar(v, name, it, units, dim)            ! scalar form, W:162
     real, intent(in) :: v
     character(*), intent(in) :: name, units, dim
     integer, intent(in) :: it
-    n_scalar = mod(n_scalar, 8) + 1
-    last_scalar(n_scalar) = v
-    if (.false.) print *, name, it, units, dim
+    call put('scalar', name, 0, 0, dble(v), units, dim)
+    if (.false.) print *, it
   end subroutine save_dg_scalar
-  subroutine save_dg_1d(v, name, it, units, dim)
+  subroutine save_dg_1d(v, name, it, units, dim)                ! 1-D form, W:255
     real, intent(in) :: v(:)
     character(*), intent(in) :: name, units, dim
     integer, intent(in) :: it
-    if (.false.) print *, v(1), name, it, units, dim
+    integer :: i
+    do i = 1, size(v)
+       call put('array', name, 0, i, dble(v(i)), units, dim)
+    end do
+    if (.false.) print *, it
   end subroutine save_dg_1d
+  subroutine save_dg_k_dp(k, v, name, it, units, dim)           ! per-level rate form, nx == 1 (M:2967)
+    integer, intent(in) :: k, it
+    double precision, intent(in) :: v
+    character(*), intent(in) :: name, units, dim
+    call put('k', name, k, 0, v, units, dim)
+    if (.false.) print *, it
+  end subroutine save_dg_k_dp
+  subroutine save_dg_ki_dp(k, i, v, name, it, units, dim)       ! per-level rate form, nx > 1 (M:3044)
+    integer, intent(in) :: k, i, it
+    double precision, intent(in) :: v
+    character(*), intent(in) :: name, units, dim
+    call put('ki', name, k, i, v, units, dim)
+    if (.false.) print *, it
+  end subroutine save_dg_ki_dp
+  subroutine dump_log(path)
+    character(*), intent(in) :: path
+    integer :: n
+    open(21, file=path, status='replace')
+    do n = 1, nlog
+       write(21,'(a,1x,a,1x,i0,1x,i0,1x,es25.17,1x,a,1x,a)') trim(log_form(n)), trim(log_name(n)), log_k(n), log_i(n), &
+            log_v(n), trim(log_units(n)), trim(log_dim(n))
+    end do
+    close(21)
+  end subroutine dump_log
 end module diagnostics
 
 module column_variables
