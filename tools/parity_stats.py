@@ -1,8 +1,18 @@
 #!/usr/bin/env python
-"""Parity statistics of the HIP path vs the CPU oracle on a large sample (SURVEY 9e asks for more than a max):
-per variable the max and the 99.9th percentile of |x-ref|/max(|ref|,floor) after ONE step from identical
-inputs, the share of levels excluded as chaotic in the reference, and the share of columns whose every
-conditioned level is within 1e-10."""
+"""Parity statistics of the HIP path vs the CPU oracle on a large sample (SURVEY 9e asks for more than a max).
+One step from identical inputs, tests/parity.py's branch-aware comparison (NO level excluded):
+
+  line 1 per workload   per variable the max and the 99.9th percentile of |x-ref|/max(|ref|,floor); how many levels
+                        sit on the reference's residue-decided tests (M:3587/M:3596) and how many of those match
+                        neither outcome; the share of columns with every level within 1e-10 (or 10x the oracle's own
+                        sensitivity there)
+  "tail" lines          every level beyond 1e-10: the HIP deviation NEXT TO the oracle's own response at that level to
+                        2-4 ulp perturbations of T and q -- evidence for "conditioning of the scheme, not arithmetic
+                        of the port": if the oracle itself moves by as much when its input moves by an ulp, no
+                        implementation can do better there.
+
+    python tools/parity_stats.py [--ncol 20000] > profiles/rNN_parity_stats.jsonl
+"""
 import argparse
 import json
 import os
@@ -16,32 +26,46 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
 from kid_amd import ThompsonMP  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
-from parity import FLOORS, OUT, TOL, conditioned_mask  # noqa: E402
+from parity import FLOORS, OUT, TOL, branch_aware_compare, verdict  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ncol", type=int, default=20000)
+    ap.add_argument("--max-tail", type=int, default=60)
     args = ap.parse_args()
     for name, warm in (("config2", True), ("config3", False), ("config5", False)):
         st = getattr(cases, name)(args.ncol if name != "config2" else 2000)
         o, m = Oracle(iiwarm=warm), ThompsonMP(iiwarm=warm)
-        ref = {k: v.copy() for k, v in st.items()}
-        rppt = o.batch_step(ref, 10.0)
-        mask = conditioned_mask(o, st, 10.0, ref)
         got = {k: v.copy() for k, v in st.items()}
         gppt, _ = m.batch_step_host(got, 10.0)
-        per, worst_col = {}, np.zeros(st["qv"].shape[0])
+        cmp = branch_aware_compare(o, st, 10.0, got, gppt, nperturb=4)
+        v = verdict(cmp)
+        err, sens, flags, ref = cmp["err"], cmp["sens"], cmp["flags"], cmp["ref"]
+        per = {}
+        unflagged = flags == 0
         for k in OUT:
-            e = np.where(mask, np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), FLOORS[k]), 0.0)
+            e = np.where(unflagged, np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), FLOORS[k]), 0.0)
             per[k] = {"max": float(e.max()), "q999": float(np.quantile(e, 0.999))}
-            worst_col = np.maximum(worst_col, e.max(axis=1))
-        pe = np.abs(gppt - rppt) / np.maximum(np.abs(rppt), 1e-12)
-        print(json.dumps({"workload": name, "columns": int(st["qv"].shape[0]), "per_variable": per,
-                          "precip_max_rel": float(pe.max()),
-                          "levels_excluded_frac": float((~mask).mean()),
-                          "columns_within_1e-10_frac": float((worst_col < TOL).mean()),
-                          "max_rel_overall": float(worst_col.max())}))
+        lim = np.maximum(TOL, 10.0 * sens)
+        print(json.dumps({"workload": name, "columns": int(err.shape[0]), "levels": int(err.size),
+                          "per_variable_levels_off_the_residue_tests": per,
+                          "precip_max_rel": v.get("max_rel_ppt"),
+                          "levels_on_residue_tests": v["n_branch_levels"],
+                          "levels_matching_neither_outcome_or_beyond_10x_sensitivity": v["n_unmatched"],
+                          "max_rel_all_levels_best_outcome": v["max_err_any"],
+                          "levels_beyond_1e-10": int((err > TOL).sum()),
+                          "columns_within_1e-10_frac": float((err <= TOL).all(axis=1).mean()),
+                          "columns_within_1e-10_or_10x_sensitivity_frac": float((err <= lim).all(axis=1).mean())}))
+        idx = np.argwhere(err > TOL)
+        order = np.argsort(-err[err > TOL])[: args.max_tail]
+        for c, k in idx[order]:
+            worst = max(OUT, key=lambda n: abs(got[n][c, k] - ref[n][c, k]) / max(abs(ref[n][c, k]), FLOORS[n]))
+            print(json.dumps({"tail": name, "column": int(c), "level": int(k), "hip_vs_oracle": float(err[c, k]),
+                              "oracle_vs_oracle_under_ulp_perturbation": float(sens[c, k]),
+                              "ratio": float(err[c, k] / max(sens[c, k], 1e-300)), "on_residue_test": int(flags[c, k]),
+                              "worst_variable": worst, "T": float(st["t"][c, k]), "qv": float(st["qv"][c, k]),
+                              "qc_in": float(st["qc"][c, k]), "qc_out": float(ref["qc"][c, k])}))
         o.close(); m.close()
 
 
