@@ -27,7 +27,7 @@ _dp = C.POINTER(C.c_double)
 def build(force=False):
     """Compile oracle/libthompson_oracle.so with gcc (building the checker)."""
     srcs = [os.path.join(_HERE, f) for f in (
-        "thompson_oracle_init.c", "thompson_oracle_column.c",
+        "thompson_oracle_init.c", "thompson_oracle_column.c", "thompson_oracle_p32n.c",
         "thompson_oracle.h", "thompson_oracle_internal.h", "Makefile")]
     if (not force and os.path.exists(_LIB)
             and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
@@ -59,6 +59,18 @@ def lib():
         L.th_oracle_batch_force.restype = C.c_int
         L.th_oracle_batch_force.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_double] + [_dp] * 16 + [
             C.c_int, C.POINTER(C.c_int), C.c_int]
+        _fp = C.POINTER(C.c_float)
+        L.th_oracle_batch_force_p32n.restype = C.c_int
+        L.th_oracle_batch_force_p32n.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_float] + [_fp] * 16 + [
+            C.c_int, C.POINTER(C.c_int), C.c_int]
+        L.th_oracle_mp_thompson_force_p32n.restype = C.c_int
+        L.th_oracle_mp_thompson_force_p32n.argtypes = [C.c_void_p] + [_fp] * 16 + [
+            C.c_int, C.c_float, _dp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+        L.th_oracle_kid_interface_p32n.restype = C.c_int
+        L.th_oracle_kid_interface_p32n.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float] + [_fp] * 15
+        for f in ("th_oracle_view_const", "th_oracle_view_const_p32n"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [C.c_void_p, C.c_char_p, C.c_int]
         L.th_oracle_default_aerosols.argtypes = [C.c_void_p, C.c_int] + [_dp] * 6
         L.th_oracle_kid_interface.restype = C.c_int
         L.th_oracle_kid_interface.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double,
@@ -139,6 +151,52 @@ class Oracle:
                                     *[_p(st[k]) for k in FORCING], _p(ppt), nthreads or self.nthreads,
                                     flags.ctypes.data_as(C.POINTER(C.c_int)) if want_illcond else None, int(force))
         return (ppt, flags) if want_illcond else ppt
+
+    # -- P32n: the reference's native arithmetic (REAL = binary32) ------------
+    def batch_step_p32n(self, st, dt, nthreads=None):
+        """In-place step of float32 [ncol, nz] arrays in the reference's native arithmetic; returns ppt float32 [ncol, 4]."""
+        ncol, nz = st["qv"].shape
+        fp = C.POINTER(C.c_float)
+        for k in STATE + FORCING:
+            assert st[k].dtype == np.float32 and st[k].flags.c_contiguous and st[k].shape == (ncol, nz), k
+        ppt = np.zeros((ncol, 4), dtype=np.float32)
+        lib().th_oracle_batch_force_p32n(self._h, ncol, nz, float(dt), *[st[k].ctypes.data_as(fp) for k in STATE],
+                                         *[st[k].ctypes.data_as(fp) for k in FORCING], ppt.ctypes.data_as(fp),
+                                         nthreads or self.nthreads, None, 0)
+        return ppt
+
+    def column_step_p32n(self, st, dt, want_rates=False):
+        """One float32 column in place; returns (ppt[4] float32, rates float64 [36, nz] or None, nstep[4], no_micro)."""
+        nz = st["qv"].shape[0]
+        fp = C.POINTER(C.c_float)
+        for k in STATE + FORCING:
+            assert st[k].dtype == np.float32 and st[k].flags.c_contiguous and st[k].shape == (nz,), k
+        ppt = np.zeros(4, dtype=np.float32)
+        rates = np.zeros((NRATES, nz)) if want_rates else None
+        nstep = (C.c_int * 4)()
+        rc = lib().th_oracle_mp_thompson_force_p32n(
+            self._h, *[st[k].ctypes.data_as(fp) for k in STATE], *[st[k].ctypes.data_as(fp) for k in FORCING],
+            ppt.ctypes.data_as(fp), nz, float(dt), _p(rates) if want_rates else None, nstep, None, 0)
+        if rc < 0:
+            raise MemoryError
+        return ppt, rates, list(nstep), bool(rc)
+
+    def kid_interface_p32n(self, nz, nx, dt, p0, r_on_cp, theta, dtheta_adv, dtheta_div, exner, dz,
+                           qv, dqv_adv, dqv_div, hydro, dhydro_adv, dhydro_div):
+        """The KiD adapter (W:28-310) with 4-byte REALs throughout, as KiD's default build runs it."""
+        fp = C.POINTER(C.c_float)
+        dth = np.zeros(nz * nx, dtype=np.float32); dqv = np.zeros(nz * nx, dtype=np.float32)
+        dhy = np.zeros(nz * nx * 10, dtype=np.float32); ppt = np.zeros(4 * nx, dtype=np.float32)
+        args = [np.ascontiguousarray(a, dtype=np.float32).ravel() for a in (
+            theta, dtheta_adv, dtheta_div, exner, dz, qv, dqv_adv, dqv_div, hydro, dhydro_adv, dhydro_div)]
+        lib().th_oracle_kid_interface_p32n(self._h, nz, nx, float(dt), float(p0), float(r_on_cp),
+                                           *[a.ctypes.data_as(fp) for a in args], dth.ctypes.data_as(fp),
+                                           dqv.ctypes.data_as(fp), dhy.ctypes.data_as(fp), ppt.ctypes.data_as(fp))
+        return dth, dqv, dhy, ppt.reshape(4, nx)
+
+    def view_const(self, name, idx=0, p32n=False):
+        f = lib().th_oracle_view_const_p32n if p32n else lib().th_oracle_view_const
+        return f(self._h, name.encode(), int(idx))
 
     def default_aerosols(self, qv, t, p):
         nz = qv.shape[-1]

@@ -8,6 +8,8 @@
  * Arithmetic model: "P64" of SURVEY.md section 8c -- every REAL and DOUBLE
  * PRECISION is IEEE binary64 and every literal is the binary64 nearest to its
  * decimal text (what `flang -fdefault-real-8 -fdefault-double-8` produces).
+ * The *_p32n entry points run the same source in the reference's native "P32n"
+ * arithmetic (REAL = binary32), for the config-5 precision sweep.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.  The shipped path (kid_amd/) never links or calls it.
@@ -111,6 +113,30 @@ int th_oracle_batch_force(const th_oracle *o, long ncol, int nz, double dt,
                           double *nc, double *nwfa, double *nifa, double *t,
                           const double *p, const double *w, const double *dz,
                           double *ppt, int nthreads, int *illcond /* [ncol*nz] or NULL */, int force);
+
+/* ---- P32n: the reference's native arithmetic (REAL = binary32, DOUBLE PRECISION = binary64; see the header of
+ * thompson_oracle_column.c).  Same entry points on float arrays; rates stay double (they are DOUBLE PRECISION). */
+int th_oracle_mp_thompson_force_p32n(const th_oracle *o,
+                                     float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, float *qg1d,
+                                     float *ni1d, float *nr1d, float *nc1d, float *nwfa1d, float *nifa1d, float *t1d,
+                                     const float *p1d, const float *w1d, const float *dzq, float ppt[4],
+                                     int nz, float dt, double *rates, int *nstep_out, int *illcond, int force);
+int th_oracle_batch_force_p32n(const th_oracle *o, long ncol, int nz, float dt,
+                               float *qv, float *qc, float *qi, float *qr, float *qs, float *qg, float *ni, float *nr,
+                               float *nc, float *nwfa, float *nifa, float *t,
+                               const float *p, const float *w, const float *dz,
+                               float *ppt, int nthreads, int *illcond, int force);
+void th_oracle_default_aerosols_p32n(const th_oracle *o, int nz, const float *qv1d, const float *t1d, const float *p1d,
+                                     float *nc1d, float *nwfa1d, float *nifa1d);
+int th_oracle_kid_interface_p32n(const th_oracle *o, int nz, int nx, float dt, float p0, float r_on_cp,
+                                 const float *theta, const float *dtheta_adv, const float *dtheta_div,
+                                 const float *exner, const float *dz, const float *qv, const float *dqv_adv,
+                                 const float *dqv_div, const float *hydro, const float *dhydro_adv,
+                                 const float *dhydro_div, float *dtheta_mphys, float *dqv_mphys,
+                                 float *dhydro_mphys, float *ppt);
+/* the constants mp_thompson reads in each arithmetic, by name (tests): -1e30 if unknown */
+double th_oracle_view_const(const th_oracle *o, const char *name, int idx);
+double th_oracle_view_const_p32n(const th_oracle *o, const char *name, int idx);
 
 /* Non-aerosol defaults for the inputs the KiD wrapper leaves unset
  * (decision U2 of SURVEY 8c; formulas of M:958-964). */

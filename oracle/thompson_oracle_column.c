@@ -16,69 +16,106 @@
  *   U4  t_Efrw/t_Efsw second index INT(mvd_c*1e6) is clamped to 1..100
  *       (the reference reads out of bounds beyond).
  */
+/*
+ * TWO ARITHMETIC MODELS FROM ONE SOURCE.  This file is compiled twice (oracle/Makefile):
+ *   P64   (default)   every REAL and DOUBLE PRECISION of the reference is binary64 -- the parity target;
+ *   P32n  (-DTH_P32N -fsingle-precision-constant, through thompson_oracle_p32n.c) the reference AS SHIPPED:
+ *         every variable the Fortran declares REAL (M:1168-1177 dummies, M:1181-1182 tendencies,
+ *         M:1215-1253 work arrays and scalars, RSLF/RSIF, module PARAMETERs M:30-176) is binary32, every
+ *         DOUBLE PRECISION one (the ~70 process rates M:1184-1211, ilamr/ilamg/N0_r/N0_g M:1225,
+ *         N0_exp/lam_exp/lamc/lamr/lamg/lami/ilami M:1235-1236, the bins Dr/Ds M:206-212, the lookup tables
+ *         M:324-340) stays binary64, unsuffixed literals are binary32 like Fortran's, and C's usual
+ *         arithmetic conversions then reproduce Fortran's mixed-mode rules (REAL op DOUBLE -> DOUBLE);
+ *         <tgmath.h> picks expf/powf/logf... for REAL arguments exactly where the Fortran generic intrinsics
+ *         do.  Entry points carry the suffix _p32n and take float arrays.
+ */
 #include "thompson_oracle_internal.h"
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef TH_P32N
+#include <tgmath.h>
+typedef float real;
+#define P(name) name##_p32n
+#else
+typedef double real;
+#define P(name) name
+#endif
+
+/* real**integer for a REAL base (compiler-rt __powisf2 in P32n, __powidf2 in P64), e.g. 10.**nn at M:1766 */
+static inline real th_powi_r(real a, int b)
+{
+    const int recip = b < 0;
+    real r = 1.0;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? (real)1.0 / r : r;
+}
 
 /* RSLF M:4656-4686 */
-double th_oracle_rslf(double P, double T)
+static real rslf(real P, real T)
 {
-    const double C0 = .611583699E03, C1 = .444606896E02, C2 = .143177157E01,
+    const real C0 = .611583699E03, C1 = .444606896E02, C2 = .143177157E01,
                  C3 = .264224321E-1, C4 = .299291081E-3, C5 = .203154182E-5,
                  C6 = .702620698E-8, C7 = .379534310E-11, C8 = -.321582393E-13;
-    double X = MAXD(-80., T - 273.16);
-    double ESL = C0 + X * (C1 + X * (C2 + X * (C3 + X * (C4 + X * (C5 + X * (C6 + X * (C7 + X * C8)))))));
+    real X = MAXD(-80., T - 273.16);
+    real ESL = C0 + X * (C1 + X * (C2 + X * (C3 + X * (C4 + X * (C5 + X * (C6 + X * (C7 + X * C8)))))));
     ESL = MIND(ESL, P * 0.15);
     return .622 * ESL / (P - ESL);
 }
 /* RSIF M:4691-4717 */
-double th_oracle_rsif(double P, double T)
+static real rsif(real P, real T)
 {
-    const double C0 = .609868993E03, C1 = .499320233E02, C2 = .184672631E01,
+    const real C0 = .609868993E03, C1 = .499320233E02, C2 = .184672631E01,
                  C3 = .402737184E-1, C4 = .565392987E-3, C5 = .521693933E-5,
                  C6 = .307839583E-7, C7 = .105785160E-9, C8 = .161444444E-12;
-    double X = MAXD(-80., T - 273.16);
-    double ESI = C0 + X * (C1 + X * (C2 + X * (C3 + X * (C4 + X * (C5 + X * (C6 + X * (C7 + X * C8)))))));
+    real X = MAXD(-80., T - 273.16);
+    real ESI = C0 + X * (C1 + X * (C2 + X * (C3 + X * (C4 + X * (C5 + X * (C6 + X * (C7 + X * C8)))))));
     ESI = MIND(ESI, P * 0.15);
     return .622 * ESI / (P - ESI);
 }
-#define rslf th_oracle_rslf
-#define rsif th_oracle_rsif
+#ifndef TH_P32N
+double th_oracle_rslf(double P_, double T) { return rslf(P_, T); }
+double th_oracle_rsif(double P_, double T) { return rsif(P_, T); }
+#endif
 
 /* Eff_aero M:4354-4390.  Its results only reach nwfaten/nifaten under
  * is_aerosol_aware (M:2398-2408): dead here, restated for cost fidelity. */
-static double Eff_aero(double D, double Da, double visc, double rhoa, double Temp, char species)
+static real Eff_aero(real D, real Da, real visc, real rhoa, real Temp, char species)
 {
-    const double boltzman = 1.3806503E-23, meanPath = 0.0256E-6;
-    double vt = 1.;
+    const real boltzman = 1.3806503E-23, meanPath = 0.0256E-6;
+    real vt = 1.;
     if (species == 'r')
         vt = -0.1021 + 4.932E3 * D - 0.9551E6 * D * D + 0.07934E9 * D * D * D - 0.002362E12 * D * D * D * D;
     else if (species == 's')
         vt = av_s * pow(D, bv_s);
     else if (species == 'g')
         vt = av_g * pow(D, bv_g);
-    double Cc = 1. + 2. * meanPath / Da * (1.257 + 0.4 * exp(-0.55 * Da / meanPath));
-    double diff = boltzman * Temp * Cc / (3. * PI * visc * Da);
-    double Re = 0.5 * rhoa * D * vt / visc;
-    double Sc_ = visc / (rhoa * diff);
-    double St = Da * Da * vt * 1000. / (9. * visc * D);
-    double aval = 1. + log(1. + Re);
-    double St2 = (1.2 + 1. / 12. * aval) / (1. + aval);
-    double Eff = 4. / (Re * Sc_) * (1. + 0.4 * sqrt(Re) * pow(Sc_, 0.3333) + 0.16 * sqrt(Re) * sqrt(Sc_))
+    real Cc = 1. + 2. * meanPath / Da * (1.257 + 0.4 * exp(-0.55 * Da / meanPath));
+    real diff = boltzman * Temp * Cc / (3. * PI * visc * Da);
+    real Re = 0.5 * rhoa * D * vt / visc;
+    real Sc_ = visc / (rhoa * diff);
+    real St = Da * Da * vt * 1000. / (9. * visc * D);
+    real aval = 1. + log(1. + Re);
+    real St2 = (1.2 + 1. / 12. * aval) / (1. + aval);
+    real Eff = 4. / (Re * Sc_) * (1. + 0.4 * sqrt(Re) * pow(Sc_, 0.3333) + 0.16 * sqrt(Re) * sqrt(Sc_))
                + 4. * Da / D * (0.02 + Da / D * (1. + 2. * sqrt(Re)));
     if (St > St2) Eff = Eff + pow((St - St2) / (St - St2 + 0.666667), 1.5);
     return MAXD(1.E-5, MIND(Eff, 1.0));
 }
 
 /* Field et al. (2005) moment fits, written out at M:1556-1626, M:2673-2711 */
-static inline double mom_loga(const double *sa, double tc0, double x)
+static inline real mom_loga(const real *sa, real tc0, real x)
 {
     return sa[1] + sa[2] * tc0 + sa[3] * x + sa[4] * tc0 * x + sa[5] * tc0 * tc0
          + sa[6] * x * x + sa[7] * tc0 * tc0 * x + sa[8] * tc0 * x * x
          + sa[9] * tc0 * tc0 * tc0 + sa[10] * x * x * x;
 }
-static inline double mom_b(const double *sb, double tc0, double x)
+static inline real mom_b(const real *sb, real tc0, real x)
 {
     return sb[1] + sb[2] * tc0 + sb[3] * x + sb[4] * tc0 * x + sb[5] * tc0 * tc0
          + sb[6] * x * x + sb[7] * tc0 * tc0 * x + sb[8] * tc0 * x * x
@@ -88,21 +125,221 @@ static inline double mom_b(const double *sb, double tc0, double x)
 /* "first of {nic-1,nic,nic+1} whose mantissa is in [1,10), else nic+1";
  * idx = INT(x/10**n) + 10*(n-n0) - (n-n0), clamped.  M:1763-1771 and its
  * seven siblings. */
-static int decade_index(double x, int nic, int n0, int ntb)
+#define DECADE_INDEX(fname, xtype)                                                                     \
+static int fname(xtype x, int nic, int n0, int ntb)                                                    \
+{                                                                                                      \
+    int n = nic - 1;                                                                                   \
+    for (int nn = nic - 1; nn <= nic + 1; nn++) {                                                      \
+        n = nn;                                                                                        \
+        if ((x / th_powi_r(10., nn)) >= 1.0 && (x / th_powi_r(10., nn)) < 10.0) break;                 \
+    }                                                                                                  \
+    int idx = (int)(x / th_powi_r(10., n)) + 10 * (n - n0) - (n - n0);                                 \
+    if (idx > ntb) idx = ntb;                                                                          \
+    if (idx < 1) idx = 1;                                                                              \
+    return idx;                                                                                        \
+}
+DECADE_INDEX(decade_index, real)       /* REAL densities: ALOG10 / REAL division, M:1763-1770 ... */
+DECADE_INDEX(decade_index_d, double)   /* DOUBLE N0_exp: DLOG10, N0_exp/10.**n with the REAL power promoted, M:1825-1832 */
+/* ------------------------------------------------------------------ */
+/* What mp_thompson reads from the module (M:25-363, values of thompson_init M:442-602), in the arithmetic of this
+ * build: everything the module declares REAL is `real` and is computed here with the statements of M:442-591 in
+ * `real` arithmetic (P32n: GAMMLN keeps its DOUBLE PRECISION internals and returns REAL, WGAMMA = EXP(GAMMLN) is a
+ * REAL exp, M:4598-4651); the DOUBLE PRECISION bins and the R8 lookup tables are shared with the context.  In the
+ * P64 build the values equal the context's own, bit for bit (tests/test_oracle_p32n.py checks that). */
+typedef struct {
+    int iiwarm, l_sediment;
+    real Nt_c, Sc3, D0i, xm0s, xm0g;
+    real sa[11], sb[11];
+    real r_c[ntb_c + 1], r_i[ntb_i + 1], r_r[ntb_r + 1], r_g[ntb_g + 1], r_s[ntb_s + 1], Nt_i[ntb_i1 + 1];
+    real cce[6][16], ccg[6][16], ocg1[16], ocg2[16];
+    real cie[8], cig[8], oig1, oig2, obmi;
+    real cre[14], crg[14], ore1, org1, org2, org3, obmr;
+    real cse[19], csg[19], oams, obms, ocms;
+    real cge[13], cgg[13], oge1, ogg1, ogg2, ogg3, oamg, obmg, ocmg;
+    real t1_qr_qc, t1_qr_qi, t2_qr_qi, t1_qg_qc, t1_qs_qc, t1_qs_qi, t1_qr_ev, t2_qr_ev;
+    real t1_qs_sd, t2_qs_sd, t1_qg_sd, t2_qg_sd, t1_qs_me, t2_qs_me, t1_qg_me, t2_qg_me;
+    int nic2, nii2, nii3, nir2, nir3, nis2, nig2, nig3;
+    const double *Dr, *Ds;
+    const double *tcg_racg, *tmr_racg, *tcr_gacr, *tmg_gacr, *tnr_racg, *tnr_gacr;
+    const double *tcs_racs1, *tmr_racs1, *tcs_racs2, *tmr_racs2, *tcr_sacr1, *tms_sacr1, *tcr_sacr2, *tms_sacr2,
+                 *tnr_racs1, *tnr_racs2, *tnr_sacr1, *tnr_sacr2;
+    const double *tpi_qcfz, *tni_qcfz, *tpi_qrfz, *tpg_qrfz, *tni_qrfz, *tnr_qrfz;
+    const double *tps_iaus, *tni_iaus, *tpi_ide, *t_Efrw, *t_Efsw;
+} th_view;
+
+/* GAMMLN M:4598-4620: REAL in, DOUBLE PRECISION inside, REAL out.  WGAMMA M:4644-4651. */
+static real gammln_r(real XX)
 {
-    int n = nic - 1;
-    for (int nn = nic - 1; nn <= nic + 1; nn++) {
-        n = nn;
-        if ((x / th_powi(10., nn)) >= 1.0 && (x / th_powi(10., nn)) < 10.0) break;
+    /* D-exponent literals: the L suffix keeps them out of -fsingle-precision-constant's reach */
+    static const double COF[6] = { (double)76.18009172947146e0L, (double)-86.50532032941677e0L, (double)24.01409824083091e0L,
+                                   (double)-1.231739572450155e0L, (double).1208650973866179e-2L, (double)-.5395239384953e-5L };
+    const double STP = (double)2.5066282746310005e0L;
+    double X = XX, Y = X, TMP = X + (double)5.5, SER;
+    TMP = (X + (double)0.5) * log(TMP) - TMP;
+    SER = (double)1.000000000190015e0L;
+    for (int J = 0; J < 6; J++) { Y = Y + (double)1.0; SER = SER + COF[J] / Y; }
+    return (real)(TMP + log(STP * SER / X));
+}
+static real wgamma_r(real y) { return exp(gammln_r(y)); }
+
+void *P(th_oracle_make_view)(const th_oracle *c)
+{
+    th_view *o = (th_view *)calloc(1, sizeof *o);
+    if (!o) return NULL;
+    o->iiwarm = c->iiwarm; o->l_sediment = c->l_sediment;
+    o->Nt_c = (real)c->set_Nc * 1.e6;                               /* M:381 */
+    for (int i = 1; i <= 10; i++) { o->sa[i] = (real)c->sa[i]; o->sb[i] = (real)c->sb[i]; }   /* REAL PARAMETERs: nearest to the text */
+    for (int i = 1; i <= ntb_c; i++) o->r_c[i] = (real)c->r_c[i];
+    for (int i = 1; i <= ntb_i; i++) o->r_i[i] = (real)c->r_i[i];
+    for (int i = 1; i <= ntb_r; i++) o->r_r[i] = (real)c->r_r[i];
+    for (int i = 1; i <= ntb_g; i++) o->r_g[i] = (real)c->r_g[i];
+    for (int i = 1; i <= ntb_s; i++) o->r_s[i] = (real)c->r_s[i];
+    for (int i = 1; i <= ntb_i1; i++) o->Nt_i[i] = (real)c->Nt_i[i];
+    /* M:442-447 */
+    o->Sc3 = pow((real)Sc, (real)1. / (real)3.);
+    o->D0i = pow((real)xm0i / (real)am_i, (real)1. / (real)bm_i);
+    o->xm0s = am_s * pow((real)D0s, (real)bm_s);
+    o->xm0g = am_g * pow((real)D0g, (real)bm_g);
+    /* M:452-465 */
+    for (int n = 1; n <= 15; n++) {
+        o->cce[1][n] = n + 1.;
+        o->cce[2][n] = bm_r + n + 1.;
+        o->cce[3][n] = bm_r + n + 4.;
+        o->cce[4][n] = n + bv_c + 1.;
+        o->cce[5][n] = bm_r + n + bv_c + 1.;
+        for (int i = 1; i <= 5; i++) o->ccg[i][n] = wgamma_r(o->cce[i][n]);
+        o->ocg1[n] = 1. / o->ccg[1][n];
+        o->ocg2[n] = 1. / o->ccg[2][n];
     }
-    int idx = (int)(x / th_powi(10., n)) + 10 * (n - n0) - (n - n0);
-    if (idx > ntb) idx = ntb;
-    if (idx < 1) idx = 1;
-    return idx;
+    /* M:467-483 */
+    o->cie[1] = mu_i + 1.;
+    o->cie[2] = bm_i + mu_i + 1.;
+    o->cie[3] = bm_i + mu_i + bv_i + 1.;
+    o->cie[4] = mu_i + bv_i + 1.;
+    o->cie[5] = mu_i + 2.;
+    o->cie[6] = bm_i * 0.5 + mu_i + bv_i + 1.;
+    o->cie[7] = bm_i * 0.5 + mu_i + 1.;
+    for (int n = 1; n <= 7; n++) o->cig[n] = wgamma_r(o->cie[n]);
+    o->oig1 = 1. / o->cig[1];
+    o->oig2 = 1. / o->cig[2];
+    o->obmi = 1. / bm_i;
+    /* M:485-505 */
+    o->cre[1] = bm_r + 1.;
+    o->cre[2] = mu_r + 1.;
+    o->cre[3] = bm_r + mu_r + 1.;
+    o->cre[4] = bm_r * 2. + mu_r + 1.;
+    o->cre[5] = mu_r + bv_r + 1.;
+    o->cre[6] = bm_r + mu_r + bv_r + 1.;
+    o->cre[7] = bm_r * 0.5 + mu_r + bv_r + 1.;
+    o->cre[8] = bm_r + mu_r + bv_r + 3.;
+    o->cre[9] = mu_r + bv_r + 3.;
+    o->cre[10] = mu_r + 2.;
+    o->cre[11] = 0.5 * (bv_r + 5. + 2. * mu_r);
+    o->cre[12] = bm_r * 0.5 + mu_r + 1.;
+    o->cre[13] = bm_r * 2. + mu_r + bv_r + 1.;
+    for (int n = 1; n <= 13; n++) o->crg[n] = wgamma_r(o->cre[n]);
+    o->obmr = 1. / bm_r;
+    o->ore1 = 1. / o->cre[1];
+    o->org1 = 1. / o->crg[1];
+    o->org2 = 1. / o->crg[2];
+    o->org3 = 1. / o->crg[3];
+    /* M:507-530 */
+    o->cse[1] = bm_s + 1.;
+    o->cse[2] = bm_s + 2.;
+    o->cse[3] = bm_s * 2.;
+    o->cse[4] = bm_s + bv_s + 1.;
+    o->cse[5] = bm_s * 2. + bv_s + 1.;
+    o->cse[6] = bm_s * 2. + 1.;
+    o->cse[7] = bm_s + mu_s + 1.;
+    o->cse[8] = bm_s + mu_s + 2.;
+    o->cse[9] = bm_s + mu_s + 3.;
+    o->cse[10] = bm_s + mu_s + bv_s + 1.;
+    o->cse[11] = bm_s * 2. + mu_s + bv_s + 1.;
+    o->cse[12] = bm_s * 2. + mu_s + 1.;
+    o->cse[13] = bv_s + 2.;
+    o->cse[14] = bm_s + bv_s;
+    o->cse[15] = mu_s + 1.;
+    o->cse[16] = 1.0 + (1.0 + bv_s) / 2.;
+    o->cse[17] = o->cse[16] + mu_s + 1.;
+    o->cse[18] = bv_s + mu_s + 3.;
+    for (int n = 1; n <= 18; n++) o->csg[n] = wgamma_r(o->cse[n]);
+    o->oams = 1. / am_s;
+    o->obms = 1. / bm_s;
+    o->ocms = pow(o->oams, o->obms);
+    /* M:532-553 */
+    o->cge[1] = bm_g + 1.;
+    o->cge[2] = mu_g + 1.;
+    o->cge[3] = bm_g + mu_g + 1.;
+    o->cge[4] = bm_g * 2. + mu_g + 1.;
+    o->cge[5] = bm_g * 2. + mu_g + bv_g + 1.;
+    o->cge[6] = bm_g + mu_g + bv_g + 1.;
+    o->cge[7] = bm_g + mu_g + bv_g + 2.;
+    o->cge[8] = bm_g + mu_g + bv_g + 3.;
+    o->cge[9] = mu_g + bv_g + 3.;
+    o->cge[10] = mu_g + 2.;
+    o->cge[11] = 0.5 * (bv_g + 5. + 2. * mu_g);
+    o->cge[12] = 0.5 * (bv_g + 5.) + mu_g;
+    for (int n = 1; n <= 12; n++) o->cgg[n] = wgamma_r(o->cge[n]);
+    o->oamg = 1. / am_g;
+    o->obmg = 1. / bm_g;
+    o->ocmg = pow(o->oamg, o->obmg);
+    o->oge1 = 1. / o->cge[1];
+    o->ogg1 = 1. / o->cgg[1];
+    o->ogg2 = 1. / o->cgg[2];
+    o->ogg3 = 1. / o->cgg[3];
+    /* rate prefactors M:560-591 */
+    o->t1_qr_qc = PI * .25 * av_r * o->crg[9];
+    o->t1_qr_qi = PI * .25 * av_r * o->crg[9];
+    o->t2_qr_qi = PI * .25 * am_r * av_r * o->crg[8];
+    o->t1_qg_qc = PI * .25 * av_g * o->cgg[9];
+    o->t1_qs_qc = PI * .25 * av_s;
+    o->t1_qs_qi = PI * .25 * av_s;
+    o->t1_qr_ev = 0.78 * o->crg[10];
+    o->t2_qr_ev = 0.308 * o->Sc3 * sqrt((real)av_r) * o->crg[11];
+    o->t1_qs_sd = 0.86;
+    o->t2_qs_sd = 0.28 * o->Sc3 * sqrt((real)av_s);
+    o->t1_qs_me = PI * 4. * C_sqrd * olfus * 0.86;
+    o->t2_qs_me = PI * 4. * C_sqrd * olfus * 0.28 * o->Sc3 * sqrt((real)av_s);
+    o->t1_qg_sd = 0.86 * o->cgg[10];
+    o->t2_qg_sd = 0.28 * o->Sc3 * sqrt((real)av_g) * o->cgg[11];
+    o->t1_qg_me = PI * 4. * C_cube * olfus * 0.86 * o->cgg[10];
+    o->t2_qg_me = PI * 4. * C_cube * olfus * 0.28 * o->Sc3 * sqrt((real)av_g) * o->cgg[11];
+    /* M:594-602 (the same integers in either arithmetic) */
+    o->nic2 = c->nic2; o->nii2 = c->nii2; o->nii3 = c->nii3; o->nir2 = c->nir2; o->nir3 = c->nir3;
+    o->nis2 = c->nis2; o->nig2 = c->nig2; o->nig3 = c->nig3;
+    o->Dr = c->Dr; o->Ds = c->Ds;
+    o->tcg_racg = c->tcg_racg; o->tmr_racg = c->tmr_racg; o->tcr_gacr = c->tcr_gacr; o->tmg_gacr = c->tmg_gacr;
+    o->tnr_racg = c->tnr_racg; o->tnr_gacr = c->tnr_gacr;
+    o->tcs_racs1 = c->tcs_racs1; o->tmr_racs1 = c->tmr_racs1; o->tcs_racs2 = c->tcs_racs2; o->tmr_racs2 = c->tmr_racs2;
+    o->tcr_sacr1 = c->tcr_sacr1; o->tms_sacr1 = c->tms_sacr1; o->tcr_sacr2 = c->tcr_sacr2; o->tms_sacr2 = c->tms_sacr2;
+    o->tnr_racs1 = c->tnr_racs1; o->tnr_racs2 = c->tnr_racs2; o->tnr_sacr1 = c->tnr_sacr1; o->tnr_sacr2 = c->tnr_sacr2;
+    o->tpi_qcfz = c->tpi_qcfz; o->tni_qcfz = c->tni_qcfz; o->tpi_qrfz = c->tpi_qrfz; o->tpg_qrfz = c->tpg_qrfz;
+    o->tni_qrfz = c->tni_qrfz; o->tnr_qrfz = c->tnr_qrfz; o->tps_iaus = c->tps_iaus; o->tni_iaus = c->tni_iaus;
+    o->tpi_ide = c->tpi_ide; o->t_Efrw = c->t_Efrw; o->t_Efsw = c->t_Efsw;
+    return o;
+}
+
+/* the view's constants by name, for tests (P64: must equal the context's; P32n: the fp32 values) */
+double P(th_oracle_view_const)(const th_oracle *c, const char *name, int idx)
+{
+    const th_view *o = (const th_view *)c->P(view);
+#define VC(n) if (!strcmp(name, #n)) return (double)o->n
+#define VA(n) if (!strcmp(name, #n)) return (double)o->n[idx]
+    VC(Nt_c); VC(Sc3); VC(D0i); VC(xm0s); VC(xm0g); VC(oig1); VC(oig2); VC(org1); VC(org2); VC(org3); VC(oams);
+    VC(ocms); VC(ocmg); VC(ogg1); VC(ogg2); VC(ogg3); VC(t1_qr_qc); VC(t2_qr_qi); VC(t1_qg_qc); VC(t1_qr_ev); VC(t2_qr_ev);
+    VC(t2_qs_sd); VC(t1_qs_me); VC(t2_qs_me); VC(t1_qg_sd); VC(t2_qg_sd); VC(t1_qg_me); VC(t2_qg_me);
+    VA(cie); VA(cig); VA(cre); VA(crg); VA(cse); VA(csg); VA(cge); VA(cgg); VA(ocg1); VA(ocg2);
+    if (!strcmp(name, "ccg1")) return (double)o->ccg[1][idx];
+    if (!strcmp(name, "ccg2")) return (double)o->ccg[2][idx];
+    if (!strcmp(name, "ccg3")) return (double)o->ccg[3][idx];
+#undef VC
+#undef VA
+    return -1.0e30;
 }
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+#ifndef TH_P32N
 int th_oracle_mp_thompson(const th_oracle *o,
                           double *qv1d, double *qc1d, double *qi1d,
                           double *qr1d, double *qs1d, double *qg1d,
@@ -129,37 +366,44 @@ int th_oracle_mp_thompson_ex(const th_oracle *o,
                                        t1d, p1d, w1d, dzq, ppt, nz, dt, rates, nstep_out, illcond, 0);
 }
 
-int th_oracle_mp_thompson_force(const th_oracle *o,
-                                double *qv1d, double *qc1d, double *qi1d,
-                                double *qr1d, double *qs1d, double *qg1d,
-                                double *ni1d, double *nr1d, double *nc1d,
-                                double *nwfa1d, double *nifa1d, double *t1d,
-                                const double *p1d, const double *w1d,
-                                const double *dzq, double ppt[4],
-                                int nz, double dt, double *rates, int *nstep_out, int *illcond, int force)
+#endif
+
+/* mp_thompson, M:1156-3688.  Dummies are REAL (M:1168-1177); rates (oracle-only output) are the DOUBLE PRECISION
+ * process rates as passed to save_dg (M:2967-3119). */
+int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
+                                real *qv1d, real *qc1d, real *qi1d,
+                                real *qr1d, real *qs1d, real *qg1d,
+                                real *ni1d, real *nr1d, real *nc1d,
+                                real *nwfa1d, real *nifa1d, real *t1d,
+                                const real *p1d, const real *w1d,
+                                const real *dzq, real ppt[4],
+                                int nz, real dt, double *rates, int *nstep_out, int *illcond, int force)
 {
+    const th_view *o = (const th_view *)ctx->P(view);
     (void)w1d;   /* only read by activ_ncloud (aerosol-aware, M:2797) */
     const int kts = 0, kte = nz - 1;
-    const size_t NA = 160;
-    double *ws = (double *)calloc(NA * (size_t)(nz + 2), sizeof(double));
+    const size_t NA = 100, ND = 80;
+    real *ws = (real *)calloc(NA * (size_t)(nz + 2), sizeof(real));          /* REAL work arrays */
+    double *wd = (double *)calloc(ND * (size_t)(nz + 2), sizeof(double));    /* DOUBLE PRECISION work arrays */
     int *Lws = (int *)calloc(5 * (size_t)nz, sizeof(int));
-    if (!ws || !Lws) { free(ws); free(Lws); return -1; }
-    size_t wi = 0;
-#define A(name) double *name = ws + (wi++) * (size_t)(nz + 2)
+    if (!ws || !wd || !Lws) { free(ws); free(wd); free(Lws); return -1; }
+    size_t wi = 0, di = 0;
+#define A(name) real *name = ws + (wi++) * (size_t)(nz + 2)
+#define AD(name) double *name = wd + (di++) * (size_t)(nz + 2)
     /* tendencies M:1181-1182 */
     A(tten); A(qvten); A(qcten); A(qiten); A(qrten); A(qsten); A(qgten);
     A(niten); A(nrten); A(ncten); A(nwfaten); A(nifaten);
     /* rates M:1184-1211 */
-    A(prw_vcd); A(pnc_wcd); A(pnc_wau); A(pnc_rcw); A(pnc_scw); A(pnc_gcw);
-    A(pna_rca); A(pna_sca); A(pna_gca); A(pnd_rcd); A(pnd_scd); A(pnd_gcd);
-    A(prr_wau); A(prr_rcw); A(prr_rcs); A(prr_rcg); A(prr_sml); A(prr_gml);
-    A(prr_rci); A(prv_rev); A(pnr_wau); A(pnr_rcs); A(pnr_rcg); A(pnr_rci);
-    A(pnr_sml); A(pnr_gml); A(pnr_rev); A(pnr_rcr); A(pnr_rfz);
-    A(pri_inu); A(pni_inu); A(pri_ihm); A(pni_ihm); A(pri_wfz); A(pni_wfz);
-    A(pri_rfz); A(pni_rfz); A(pri_ide); A(pni_ide); A(pri_rci); A(pni_rci);
-    A(pni_sci); A(pni_iau); A(pri_iha); A(pni_iha);
-    A(prs_iau); A(prs_sci); A(prs_rcs); A(prs_scw); A(prs_sde); A(prs_ihm); A(prs_ide);
-    A(prg_scw); A(prg_rfz); A(prg_gde); A(prg_gcw); A(prg_rci); A(prg_rcs); A(prg_rcg); A(prg_ihm);
+    AD(prw_vcd); AD(pnc_wcd); AD(pnc_wau); AD(pnc_rcw); AD(pnc_scw); AD(pnc_gcw);
+    AD(pna_rca); AD(pna_sca); AD(pna_gca); AD(pnd_rcd); AD(pnd_scd); AD(pnd_gcd);
+    AD(prr_wau); AD(prr_rcw); AD(prr_rcs); AD(prr_rcg); AD(prr_sml); AD(prr_gml);
+    AD(prr_rci); AD(prv_rev); AD(pnr_wau); AD(pnr_rcs); AD(pnr_rcg); AD(pnr_rci);
+    AD(pnr_sml); AD(pnr_gml); AD(pnr_rev); AD(pnr_rcr); AD(pnr_rfz);
+    AD(pri_inu); AD(pni_inu); AD(pri_ihm); AD(pni_ihm); AD(pri_wfz); AD(pni_wfz);
+    AD(pri_rfz); AD(pni_rfz); AD(pri_ide); AD(pni_ide); AD(pri_rci); AD(pni_rci);
+    AD(pni_sci); AD(pni_iau); AD(pri_iha); AD(pni_iha);
+    AD(prs_iau); AD(prs_sci); AD(prs_rcs); AD(prs_scw); AD(prs_sde); AD(prs_ihm); AD(prs_ide);
+    AD(prg_scw); AD(prg_rfz); AD(prg_gde); AD(prg_gcw); AD(prg_rci); AD(prg_rcs); AD(prg_rcg); AD(prg_ihm);
     /* state M:1215-1241 */
     A(temp); A(pres); A(qv);
     A(rc); A(ri); A(rr); A(rs); A(rg); A(ni); A(nr); A(nc); A(nwfa); A(nifa);
@@ -167,45 +411,47 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
     A(qvs); A(qvsi); A(delQvs);
     A(satw); A(sati); A(ssatw); A(ssati);
     A(diffu); A(visco); A(vsc2); A(tcond); A(lvap); A(ocp); A(lvt2);
-    A(ilamr); A(ilamg); A(N0_r); A(N0_g);
+    AD(ilamr); AD(ilamg); AD(N0_r); AD(N0_g);          /* DOUBLE PRECISION, M:1225 */
     A(mvd_r); A(mvd_c);
     A(smob); A(smo2); A(smo1); A(smo0); A(smoc); A(smod); A(smoe); A(smof);
     A(sed_r); A(sed_s); A(sed_g); A(sed_i); A(sed_n);
     A(vtik); A(vtnik); A(vtrk); A(vtnrk); A(vtsk); A(vtgk);
     A(vts_boost);
 #undef A
+#undef AD
     int *L_qc = Lws, *L_qi = Lws + nz, *L_qr = Lws + 2 * nz, *L_qs = Lws + 3 * nz, *L_qg = Lws + 4 * nz;
 
-    const double *cce2 = o->cce[2], *ccg1 = o->ccg[1], *ccg2 = o->ccg[2], *ccg3 = o->ccg[3];
-    const double *ocg1 = o->ocg1, *ocg2 = o->ocg2;
-    const double *cie = o->cie, *cig = o->cig, *cre = o->cre, *crg = o->crg,
+    const real *cce2 = o->cce[2], *ccg1 = o->ccg[1], *ccg2 = o->ccg[2], *ccg3 = o->ccg[3];
+    const real *ocg1 = o->ocg1, *ocg2 = o->ocg2;
+    const real *cie = o->cie, *cig = o->cig, *cre = o->cre, *crg = o->crg,
                  *cse = o->cse, *csg = o->csg, *cge = o->cge, *cgg = o->cgg;
-    const double oig1 = o->oig1, oig2 = o->oig2, obmi = o->obmi, obmr = o->obmr,
+    const real oig1 = o->oig1, oig2 = o->oig2, obmi = o->obmi, obmr = o->obmr,
                  org1 = o->org1, org2 = o->org2, org3 = o->org3, oams = o->oams,
                  oge1 = o->oge1, ogg1 = o->ogg1, ogg2 = o->ogg2, ogg3 = o->ogg3, obmg = o->obmg;
-    const double Nt_c = o->Nt_c, D0i = o->D0i;
+    const real Nt_c = o->Nt_c, D0i = o->D0i;
     const int iiwarm = o->iiwarm;
-    const double DT = dt;
+    const real DT = dt;
 
-    double rgvm, delta_tp, orho, lfus2;
-    double onstep[6];
-    double N0_exp, N0_min, lam_exp, lamc = 0., lamr, lamg;
-    double lami, ilami;
-    double xDc = 0., Dc_b, Dc_g, xDi, xDs, xDg;
-    double zeta1, zeta, taud, tau;
-    double stoke_g;
-    double vti, vtr, vts, vtg;
-    double Mrat, ils1, ils2, t1_vts, t2_vts, t3_vts, t4_vts, C_snow;
-    double a_, b_, loga_, tf;
-    double tempc = 0., tc0;
-    double xnc, xri, xni, xmi, oxmi, xrc, xrr, xnr;
-    double xsat, rate_max, sump, ratio;
-    double clap, fcd, dfcd;
-    double otemp, rvs, rvs_p, rvs_pp, gamsc, alphsc, t1_evap, t1_subl;
-    double r_frac, g_frac;
-    double Ef_rw, Ef_sw, Ef_gw = 0., Ef_rr, Ef_ra, Ef_sa, Ef_ga;
-    double dtsave, odts, odt, odzq;
-    double xslw1, ygra1, zans1, eva_factor;
+    /* scalar locals with the types of M:1233-1253 */
+    real rgvm, delta_tp, orho, lfus2;
+    real onstep[6];
+    double N0_exp, N0_min, lam_exp, lamc = 0., lamr, lamg;      /* DOUBLE PRECISION, M:1235 */
+    double lami, ilami;                                         /* DOUBLE PRECISION, M:1236 */
+    real xDc = 0., Dc_b, Dc_g, xDi, xDs, xDg;
+    real zeta1, zeta, taud, tau;
+    real stoke_g;
+    real vti, vtr, vts, vtg;
+    real Mrat, ils1, ils2, t1_vts, t2_vts, t3_vts, t4_vts, C_snow;
+    real a_, b_, loga_, tf;
+    real tempc = 0., tc0;
+    real xnc, xri, xni, xmi, oxmi, xrc, xrr, xnr;
+    real xsat, rate_max, sump, ratio;                           /* M:1246: REAL even though they scale DOUBLE rates */
+    real clap, fcd, dfcd;
+    real otemp, rvs, rvs_p, rvs_pp, gamsc, alphsc, t1_evap, t1_subl;
+    real r_frac, g_frac;
+    real Ef_rw, Ef_sw, Ef_gw = 0., Ef_rr, Ef_ra, Ef_sa, Ef_ga;
+    real dtsave, odts, odt, odzq;
+    real xslw1, ygra1, zans1, eva_factor;
     int k, n, nstep, k_0, idx, nu_c = 12;
     int ksed1[6];
     int idx_tc, idx_t, idx_s, idx_g1, idx_g, idx_r1, idx_r, idx_i1, idx_i, idx_c;
@@ -356,7 +602,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
         tcond[k] = (5.69 + 0.0168 * tempc) * 1.0E-5 * 418.936;
     }
 
-    if (no_micro) { free(ws); free(Lws); return 1; }          /* M:1540 */
+    if (no_micro) { free(ws); free(wd); free(Lws); return 1; }          /* M:1540 */
 
     /* ---- D: snow moments, M:1545-1628 ---- */
     if (!iiwarm) {
@@ -515,7 +761,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
                 lamr = 1. / ilamr[k];
                 lam_exp = lamr * pow(crg[3] * org2 * org1, bm_r);
                 N0_exp = org1 * rr[k] / am_r * pow(lam_exp, cre[1]);
-                idx_r1 = decade_index(N0_exp, NINT(log10(N0_exp)), o->nir3, ntb_r1);
+                idx_r1 = decade_index_d(N0_exp, NINT(log10(N0_exp)), o->nir3, ntb_r1);
             } else {
                 idx_r = 1;
                 idx_r1 = ntb_r1;
@@ -531,7 +777,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
                 lamg = 1. / ilamg[k];
                 lam_exp = lamg * pow(cgg[3] * ogg2 * ogg1, bm_g);
                 N0_exp = ogg1 * rg[k] / am_g * pow(lam_exp, cge[1]);
-                idx_g1 = decade_index(N0_exp, NINT(log10(N0_exp)), o->nig3, ntb_g1);
+                idx_g1 = decade_index_d(N0_exp, NINT(log10(N0_exp)), o->nig3, ntb_g1);
             } else {
                 idx_g = 1;
                 idx_g1 = ntb_g1;
@@ -1290,7 +1536,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
         }
     }
     if (ksed1[1] == kte) ksed1[1] = kte - 1;
-    if (nstep > 0) onstep[1] = 1. / (double)nstep;
+    if (nstep > 0) onstep[1] = 1. / (real)nstep;
 
     if (!iiwarm) {
         nstep = 0;
@@ -1315,7 +1561,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
             }
         }
         if (ksed1[2] == kte) ksed1[2] = kte - 1;
-        if (nstep > 0) onstep[2] = 1. / (double)nstep;
+        if (nstep > 0) onstep[2] = 1. / (real)nstep;
 
         nstep = 0;
         for (k = kte; k >= kts; k--) {
@@ -1347,7 +1593,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
             }
         }
         if (ksed1[3] == kte) ksed1[3] = kte - 1;
-        if (nstep > 0) onstep[3] = 1. / (double)nstep;
+        if (nstep > 0) onstep[3] = 1. / (real)nstep;
 
         nstep = 0;
         for (k = kte; k >= kts; k--) {
@@ -1369,7 +1615,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
             }
         }
         if (ksed1[4] == kte) ksed1[4] = kte - 1;
-        if (nstep > 0) onstep[4] = 1. / (double)nstep;
+        if (nstep > 0) onstep[4] = 1. / (real)nstep;
     } else {
         for (k = kte; k >= kts; k--) { vtik[k] = 0.; vtnik[k] = 0.; vtsk[k] = 0.; vtgk[k] = 0.; }
     }
@@ -1557,7 +1803,7 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
                 lami = cie[2] / 5.E-6;
             else if (xDi > 300.E-6)
                 lami = cie[2] / 300.E-6;
-            ni1d[k] = MIND(cig[1] * oig2 * qi1d[k] / am_i * pow(lami, bm_i), 499.e3 / rho[k]);
+            ni1d[k] = MIND(cig[1] * oig2 * qi1d[k] / am_i * pow(lami, bm_i), (double)499.e3 / rho[k]);   /* 499.D3/rho(k), M:3664 */
         }
         qr1d[k] = qr1d[k] + qrten[k] * DT;
         nr1d[k] = MAXD(R2 / rho[k], nr1d[k] + nrten[k] * DT);
@@ -1581,18 +1827,20 @@ int th_oracle_mp_thompson_force(const th_oracle *o,
     }
 
     free(ws);
+    free(wd);
     free(Lws);
     return 0;
 }
 
 /* non-aerosol defaults, M:958-964 (decision U2) */
-void th_oracle_default_aerosols(const th_oracle *o, int nz,
-                                const double *qv1d, const double *t1d,
-                                const double *p1d, double *nc1d,
-                                double *nwfa1d, double *nifa1d)
+void P(th_oracle_default_aerosols)(const th_oracle *ctx, int nz,
+                                const real *qv1d, const real *t1d,
+                                const real *p1d, real *nc1d,
+                                real *nwfa1d, real *nifa1d)
 {
+    const th_view *o = (const th_view *)ctx->P(view);
     for (int k = 0; k < nz; k++) {
-        double rho = 0.622 * p1d[k] / (R_gas * t1d[k] * (qv1d[k] + 0.622));
+        real rho = 0.622 * p1d[k] / (R_gas * t1d[k] * (qv1d[k] + 0.622));
         nc1d[k] = o->Nt_c / rho;
         nwfa1d[k] = 11.1E6 / rho;
         nifa1d[k] = naIN1 * 0.01 / rho;
@@ -1601,9 +1849,9 @@ void th_oracle_default_aerosols(const th_oracle *o, int nz,
 
 /* ------------------------------------------------------------------ */
 typedef struct {
-    const th_oracle *o; long c0, c1; int nz; double dt;
-    double *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;
-    const double *p, *w, *dz; double *ppt; int *illcond; int force;
+    const th_oracle *o; long c0, c1; int nz; real dt;
+    real *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;
+    const real *p, *w, *dz; real *ppt; int *illcond; int force;
 } batch_job;
 
 static void *batch_worker(void *arg)
@@ -1612,7 +1860,7 @@ static void *batch_worker(void *arg)
     const size_t nz = (size_t)b->nz;
     for (long c = b->c0; c < b->c1; c++) {
         size_t off = (size_t)c * nz;
-        th_oracle_mp_thompson_force(b->o, b->qv + off, b->qc + off, b->qi + off, b->qr + off,
+        P(th_oracle_mp_thompson_force)(b->o, b->qv + off, b->qc + off, b->qi + off, b->qr + off,
                                  b->qs + off, b->qg + off, b->ni + off, b->nr + off,
                                  b->nc + off, b->nwfa + off, b->nifa + off, b->t + off,
                                  b->p + off, b->w + off, b->dz + off, b->ppt + 4 * (size_t)c,
@@ -1621,6 +1869,7 @@ static void *batch_worker(void *arg)
     return NULL;
 }
 
+#ifndef TH_P32N
 int th_oracle_batch(const th_oracle *o, long ncol, int nz, double dt,
                     double *qv, double *qc, double *qi, double *qr,
                     double *qs, double *qg, double *ni, double *nr,
@@ -1643,12 +1892,14 @@ int th_oracle_batch_ex(const th_oracle *o, long ncol, int nz, double dt,
                                  nthreads, illcond, 0);
 }
 
-int th_oracle_batch_force(const th_oracle *o, long ncol, int nz, double dt,
-                          double *qv, double *qc, double *qi, double *qr,
-                          double *qs, double *qg, double *ni, double *nr,
-                          double *nc, double *nwfa, double *nifa, double *t,
-                          const double *p, const double *w, const double *dz,
-                          double *ppt, int nthreads, int *illcond, int force)
+#endif
+
+int P(th_oracle_batch_force)(const th_oracle *o, long ncol, int nz, real dt,
+                          real *qv, real *qc, real *qi, real *qr,
+                          real *qs, real *qg, real *ni, real *nr,
+                          real *nc, real *nwfa, real *nifa, real *t,
+                          const real *p, const real *w, const real *dz,
+                          real *ppt, int nthreads, int *illcond, int force)
 {
     if (nthreads < 1) nthreads = 1;
     if (nthreads > ncol) nthreads = (int)(ncol > 0 ? ncol : 1);
@@ -1668,21 +1919,21 @@ int th_oracle_batch_force(const th_oracle *o, long ncol, int nz, double dt,
 
 /* ------------------------------------------------------------------ */
 /* mphys_thompson09_interfacen, W:28-310 */
-int th_oracle_kid_interface(const th_oracle *o, int nz, int nx, double dt,
-                            double p0, double r_on_cp,
-                            const double *theta, const double *dtheta_adv,
-                            const double *dtheta_div, const double *exner,
-                            const double *dz, const double *qv,
-                            const double *dqv_adv, const double *dqv_div,
-                            const double *hydro, const double *dhydro_adv,
-                            const double *dhydro_div,
-                            double *dtheta_mphys, double *dqv_mphys,
-                            double *dhydro_mphys, double *ppt)
+int P(th_oracle_kid_interface)(const th_oracle *o, int nz, int nx, real dt,
+                            real p0, real r_on_cp,
+                            const real *theta, const real *dtheta_adv,
+                            const real *dtheta_div, const real *exner,
+                            const real *dz, const real *qv,
+                            const real *dqv_adv, const real *dqv_div,
+                            const real *hydro, const real *dhydro_adv,
+                            const real *dhydro_div,
+                            real *dtheta_mphys, real *dqv_mphys,
+                            real *dhydro_mphys, real *ppt)
 {
     const size_t N = (size_t)nz;
-    double *buf = (double *)calloc(16 * N, sizeof(double));
+    real *buf = (real *)calloc(16 * N, sizeof(real));
     if (!buf) return -1;
-    double *t1d = buf, *p1d = buf + N, *dzq = buf + 2 * N, *qv1d = buf + 3 * N, *qc1d = buf + 4 * N,
+    real *t1d = buf, *p1d = buf + N, *dzq = buf + 2 * N, *qv1d = buf + 3 * N, *qc1d = buf + 4 * N,
            *qr1d = buf + 5 * N, *qi1d = buf + 6 * N, *ni1d = buf + 7 * N, *qs1d = buf + 8 * N,
            *qg1d = buf + 9 * N, *nr1d = buf + 10 * N, *nc1d = buf + 11 * N, *nifa1d = buf + 12 * N,
            *nwfa1d = buf + 13 * N, *w1d = buf + 14 * N;
@@ -1690,7 +1941,7 @@ int th_oracle_kid_interface(const th_oracle *o, int nz, int nx, double dt,
 #define S(a, k, i)         (a)[(size_t)(k) + N * (size_t)(i)]
     /* qc1d..qg1d zero-initialised once, outside the i loop (W:46-52) */
     for (int i = 0; i < nx; i++) {
-        double pp[4] = { 0., 0., 0., 0. };                    /* W:55-58 */
+        real pp[4] = { 0., 0., 0., 0. };                    /* W:55-58 */
         for (int k = 0; k < nz; k++) {                         /* W:59-97 */
             t1d[k] = (S(theta, k, i) + (S(dtheta_adv, k, i) + S(dtheta_div, k, i)) * dt) * S(exner, k, i);
             p1d[k] = p0 * pow(S(exner, k, i), 1. / r_on_cp);
@@ -1708,10 +1959,10 @@ int th_oracle_kid_interface(const th_oracle *o, int nz, int nx, double dt,
             w1d[k] = 0.;
         }
         /* U2: the wrapper leaves nc1d, nwfa1d, nifa1d, w1d unset (W:36) */
-        th_oracle_default_aerosols(o, nz, qv1d, t1d, p1d, nc1d, nwfa1d, nifa1d);
+        P(th_oracle_default_aerosols)(o, nz, qv1d, t1d, p1d, nc1d, nwfa1d, nifa1d);
 
-        th_oracle_mp_thompson(o, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d,
-                              t1d, p1d, w1d, dzq, pp, nz, dt, NULL, NULL);     /* W:143-152 */
+        P(th_oracle_mp_thompson_force)(o, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d, nifa1d,
+                              t1d, p1d, w1d, dzq, pp, nz, dt, NULL, NULL, NULL, 0);     /* W:143-152 */
 
         ppt[0 * (size_t)nx + i] = pp[0];
         ppt[1 * (size_t)nx + i] = pp[1];

@@ -717,6 +717,9 @@ th_oracle *th_oracle_create(int iiwarm, double set_Nc, int l_sediment,
             if (cache_path) cache_store(o, cache_path);
         }
     }
+    o->view = th_oracle_make_view(o);
+    o->view_p32n = th_oracle_make_view_p32n(o);
+    if (!o->view || !o->view_p32n) { th_oracle_destroy(o); return NULL; }
     return o;
 }
 
@@ -725,6 +728,7 @@ void th_oracle_destroy(th_oracle *o)
     if (!o) return;
     tabent t[40]; int nt = table_list(o, t);
     for (int i = 0; i < nt; i++) free(*t[i].p);
+    free(o->view); free(o->view_p32n);
     free(o);
 }
 

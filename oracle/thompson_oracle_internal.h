@@ -125,7 +125,12 @@ struct th_oracle {
     double *tps_iaus, *tni_iaus, *tpi_ide;
     double *t_Efrw, *t_Efsw;
     int nthreads;
+    /* what mp_thompson reads, in the arithmetic of each build of thompson_oracle_column.c (th_view there) */
+    void *view, *view_p32n;
 };
+
+void *th_oracle_make_view(const struct th_oracle *c);        /* P64 build of the column file */
+void *th_oracle_make_view_p32n(const struct th_oracle *c);   /* P32n build (thompson_oracle_p32n.c) */
 
 /* column-major index helpers (1-based arguments) */
 #define IX2(i,j,n1)             ((size_t)((i)-1) + (size_t)(n1)*((j)-1))

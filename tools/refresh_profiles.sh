@@ -14,10 +14,13 @@ done
 # the bench reads profiles/<tag>_pmc_<workload>.json for the measured HBM traffic
 mkdir -p profiles && cp $out/${tag}_pmc_*.json profiles/
 for w in config2 config3 config5; do
-  python bench.py --workload $w > $out/${tag}_bench_$w.json
+  python bench.py --no-other-workloads --workload $w > $out/${tag}_bench_$w.json
   echo "bench $w: $(cut -c1-200 $out/${tag}_bench_$w.json)"
 done
-rm -rf gpurun_out/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --no-cpu-baseline > /dev/null 2>&1
-cp $(ls -t gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1) $out/${tag}_config2_kernel_stats.csv
-cat $out/${tag}_config2_kernel_stats.csv | head -5
+# rocprofv3 --kernel-trace --stats of the bench command itself, per workload (program directly after `--`)
+for w in config2 config3 config5; do
+  rm -rf gpurun_out/prof_${tag}_$w
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$w -- python3 bench.py --no-other-workloads --no-cpu-baseline --workload $w > /dev/null 2>&1
+  cp $(ls -t gpurun_out/prof_${tag}_$w/*/*kernel_stats.csv | head -1) $out/${tag}_${w}_kernel_stats.csv
+  head -3 $out/${tag}_${w}_kernel_stats.csv
+done
