@@ -9,7 +9,8 @@
  * ISO_C_BINDING (kid_amd/fortran/module_mp_thompson09n.f90).
  *
  * Conventions
- *   - All reals are IEEE binary64 ("P64" build of the reference).
+ *   - The kidmp_* entries take IEEE binary64 arrays and compute in binary64 (the "P64" build of the
+ *     reference: the parity target); the kidmp32_* entries take binary32 arrays (KiD's default REAL).
  *   - A column profile is nz contiguous values, level kts first (k fastest),
  *     i.e. exactly KiD's `theta(k,i)` storage (W:60-93).  A batch of ncol
  *     columns is x[col*nz + k].
@@ -105,6 +106,35 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
                             const double *p, const double *w, const double *dz,
                             double *ppt, double *rates, int32_t *nstep,
                             void *stream);
+
+/* ---- The same three entries on binary32 arrays: the reference's `REAL` when KiD is built with its default
+ * 4-byte reals (M:1168-1177 declares every dummy REAL).  `arith` selects the arithmetic inside the kernel:
+ *   KIDMP_ARITH_P32N  the reference as shipped: everything it declares REAL is binary32, everything it declares
+ *                     DOUBLE PRECISION (the ~70 process rates M:1184-1211, ilamr/ilamg/N0_r/N0_g M:1225, lamc/lamr/
+ *                     lamg/lami/N0_exp M:1235-1236, the lookup tables) stays binary64;
+ *   KIDMP_ARITH_F32   everything binary32 (the cheap end of the precision sweep of BASELINE config 5).
+ * rates (may be NULL) is binary64 in both.  The double entries above are the parity build (P64). */
+#define KIDMP_ARITH_P32N 0
+#define KIDMP_ARITH_F32  1
+int kidmp32_column_step(kidmp_ctx *ctx, int32_t nz, float dt,
+                        float *qv1d, float *qc1d, float *qi1d, float *qr1d,
+                        float *qs1d, float *qg1d, float *ni1d, float *nr1d,
+                        float *nc1d, float *nwfa1d, float *nifa1d, float *t1d,
+                        const float *p1d, const float *w1d, const float *dzq,
+                        float *ppt, int32_t arith);
+int kidmp32_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt,
+                            float *qv, float *qc, float *qi, float *qr,
+                            float *qs, float *qg, float *ni, float *nr,
+                            float *nc, float *nwfa, float *nifa, float *t,
+                            const float *p, const float *w, const float *dz,
+                            float *ppt, double *rates, int32_t *nstep, int32_t arith);
+int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt,
+                              float *qv, float *qc, float *qi, float *qr,
+                              float *qs, float *qg, float *ni, float *nr,
+                              float *nc, float *nwfa, float *nifa, float *t,
+                              const float *p, const float *w, const float *dz,
+                              float *ppt, double *rates, int32_t *nstep,
+                              int32_t arith, void *stream);
 
 /* Sizes the context's internal work buffer for batches of up to ncol columns of nz levels.  Optional:
  * kidmp_batch_step_device grows it on demand, but that allocates (and synchronises the device); after

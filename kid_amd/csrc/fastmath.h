@@ -187,5 +187,86 @@ KFM_FN double pow10_times_pow(double la, const Log2Parts &l, double y)
     return exp2_parts(l, y, t_hi, t_lo);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// binary32 overloads for the P32n / fp32 instantiations of the column kernel (where the reference declares a
+// variable REAL, its Fortran intrinsics are the single-precision ones).  The fp32 special-function units of CDNA
+// (v_log_f32, v_exp_f32, v_rsq_f32, v_rcp_f32: ~1 ulp) do the work; arguments are positive, finite and normal as
+// above.  Errors: sqrt, cbrt <= 1 ulp; log, log10 <= 2 ulp (absolute error 1e-7 near x = 1, as logf itself is
+// evaluated through log2); exp, exp10, pow carry the binary32 rounding of their exponent: relative error about
+// 6e-8 * (1 + |exponent in bits|), i.e. <= 3e-6 for the largest exponents of the scheme -- the same order as a
+// libm powf on an argument that was itself rounded to binary32.
+KFM_FN float log2_hw(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_logf(x);
+#else
+    return std::log2(x);
+#endif
+}
+KFM_FN float exp2_hw(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x);
+#else
+    return std::exp2(x);
+#endif
+}
+KFM_FN float log(float x) { return log2_hw(x) * 0.69314718056f; }
+KFM_FN float log10(float x) { return log2_hw(x) * 0.30102999566f; }
+// e**x = 2**(x*log2 e): the product is formed as hi + lo so that its rounding does not enter the result
+KFM_FN float exp(float x)
+{
+    const float hi = x * 1.44269504089f;
+    const float lo = std::fma(x, 1.44269504089f, -hi) + x * 1.925963033e-8f;
+    const float n = std::rint(hi);
+    return std::ldexp(exp2_hw((hi - n) + lo), int(n));
+}
+KFM_FN float exp10(float x)
+{
+    const float hi = x * 3.32192809489f;
+    const float lo = std::fma(x, 3.32192809489f, -hi) + x * 6.0576633e-8f;
+    const float n = std::rint(hi);
+    return std::ldexp(exp2_hw((hi - n) + lo), int(n));
+}
+KFM_FN float sqrt_pos(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y;                               // one Newton step on sqrt: g + (x - g^2) * y/2
+    return std::fma(std::fma(-g, g, x), 0.5f * y, g);
+#else
+    return std::sqrt(x);
+#endif
+}
+KFM_FN float cbrt_pos(float x)
+{
+    const float y = exp2_hw(-0.33333334f * log2_hw(x));  // x**(-1/3), ~1e-6
+    const float t = y * y;
+    const float c = x * t;                               // x**(1/3)
+    const float r = std::fma(-(c * c), c, x);
+    return std::fma(r, t * 0.33333334f, c);              // one Newton correction
+}
+KFM_FN float pow(float x, float y)
+{
+    const float l = log2_hw(x);
+    const float hi = y * l;
+    const float lo = std::fma(y, l, -hi);
+    const float n = std::rint(hi);
+    return std::ldexp(exp2_hw((hi - n) + lo), int(n));
+}
+struct Log2PartsF { float l; };
+KFM_FN Log2PartsF log2_parts(float x) { return Log2PartsF{log2_hw(x)}; }
+KFM_FN float pow10_times_pow(float la, const Log2PartsF &l, float y)
+{
+    const float a = la * 3.32192809489f, b = y * l.l;
+    const float hi = a + b, bb = hi - a;
+    const float lo = ((a - (hi - bb)) + (b - bb)) + (std::fma(la, 3.32192809489f, -a) + std::fma(y, l.l, -b));   // two-sum + product residuals
+    const float n = std::rint(hi);
+    return std::ldexp(exp2_hw((hi - n) + lo), int(n));
+}
+// mixed-type powers follow Fortran's promotion: REAL**DOUBLE and DOUBLE**REAL are evaluated in DOUBLE
+KFM_FN double pow(double x, float y) { return pow(x, double(y)); }
+KFM_FN double pow(float x, double y) { return pow(double(x), y); }
+
 }  // namespace fm
 }  // namespace kidmp

@@ -347,7 +347,9 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
     INITTRY(hipMemcpy(c->d_bins, &c->hb, sizeof(Bins), hipMemcpyHostToDevice));
     c->cslot = take_slot();
     if (c->cslot < 0) { g_err = "kidmp_init: more than 8 live contexts in this process"; return bail(KIDMP_ESTATE); }
-    INITTRY(upload_consts(c->cslot, c->hc));
+    INITTRY(p64::upload_consts(c->cslot, c->hc));       // one constant-memory image per arithmetic variant
+    INITTRY(p32n::upload_consts(c->cslot, c->hc));
+    INITTRY(f32::upload_consts(c->cslot, c->hc));
     INITTRY(alloc_tables(c->tables));
     INITTRY(build_tables(c->d_consts, c->d_bins, c->hc.iiwarm, c->tables, c->stream));
 #undef INITTRY
@@ -399,7 +401,7 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     if (ncol == 0) return KIDMP_OK;
     if (int rc = ensure_scratch(ctx, ncol, nz)) return rc;
     a.scratch = ctx->d_scratch;
-    HIPTRY(ctx, launch_column_step(a, (hipStream_t)stream));
+    HIPTRY(ctx, p64::launch_column_step(a, (hipStream_t)stream));
     return KIDMP_OK;
 }
 
@@ -472,6 +474,89 @@ int kidmp_column_step(kidmp_ctx *ctx, int32_t nz, double dt,
 {
     return kidmp_batch_step_host(ctx, 1, nz, dt, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d,
                                  nifa1d, t1d, p1d, w1d, dzq, ppt, nullptr);
+}
+
+// ---- binary32 state: the reference as shipped (P32n) and the all-binary32 build ----
+int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt,
+                              float *qv, float *qc, float *qi, float *qr, float *qs, float *qg,
+                              float *ni, float *nr, float *nc, float *nwfa, float *nifa, float *t,
+                              const float *p, const float *w, const float *dz,
+                              float *ppt, double *rates, int32_t *nstep, int32_t arith, void *stream)
+{
+    (void)w;
+    const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
+    if (int rc = check_step_args(ctx, ncol, nz, double(dt), ptrs, 15)) return rc;
+    if (arith != KIDMP_ARITH_P32N && arith != KIDMP_ARITH_F32) return fail(ctx, KIDMP_EINVAL, "kidmp32: arith must be KIDMP_ARITH_P32N or KIDMP_ARITH_F32");
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, qv, "qv")) return rc;
+    if (int rc = check_on_device(ctx, ppt, "ppt")) return rc;
+    StepArgsT<float> a{};
+    a.qv = qv; a.qc = qc; a.qi = qi; a.qr = qr; a.qs = qs; a.qg = qg; a.ni = ni; a.nr = nr;
+    a.nc = nc; a.nwfa = nwfa; a.nifa = nifa; a.t = t; a.p = p; a.dz = dz;
+    a.ppt = ppt; a.rates = rates; a.nstep = nstep;
+    a.cslot = ctx->cslot; a.tables = ctx->tables; a.iiwarm = ctx->cfg.iiwarm != 0;
+    a.ncol = ncol; a.nz = nz; a.dt = dt;
+    a.debug_stop = ctx->debug_stop;
+    if (ncol == 0) return KIDMP_OK;
+    if (int rc = ensure_scratch(ctx, ncol, nz)) return rc;
+    a.scratch = reinterpret_cast<float *>(ctx->d_scratch);
+    if (arith == KIDMP_ARITH_P32N) HIPTRY(ctx, p32n::launch_column_step(a, (hipStream_t)stream));
+    else                           HIPTRY(ctx, f32::launch_column_step(a, (hipStream_t)stream));
+    return KIDMP_OK;
+}
+
+int kidmp32_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt,
+                            float *qv, float *qc, float *qi, float *qr, float *qs, float *qg,
+                            float *ni, float *nr, float *nc, float *nwfa, float *nifa, float *t,
+                            const float *p, const float *w, const float *dz, float *ppt, double *rates,
+                            int32_t *nstep, int32_t arith)
+{
+    float *io[12] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t};
+    const float *in[2] = {p, dz};
+    const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
+    if (int rc = check_step_args(ctx, ncol, nz, double(dt), ptrs, 15)) return rc;
+    if (ncol == 0) return KIDMP_OK;
+    GUARD(ctx);
+    const size_t prof = size_t(ncol) * size_t(nz);
+    const size_t need = (14 * prof + 4 * size_t(ncol)) * sizeof(float) + (rates ? size_t(KIDMP_NRATES) * prof : 0) * sizeof(double)
+                        + (nstep ? 4 * size_t(ncol) * sizeof(int32_t) : 0) + 64;
+    if (need > ctx->stage_bytes) {
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr;
+        ctx->stage_bytes = 0;
+        HIPTRY(ctx, hipMalloc((void **)&ctx->d_stage, need));
+        ctx->stage_bytes = need;
+    }
+    // layout: [rates (double)] [14 profiles + ppt (float)] [nstep (int32)] -- the doubles first, for alignment
+    double *drates = rates ? ctx->d_stage : nullptr;
+    float *d = reinterpret_cast<float *>(ctx->d_stage + (rates ? size_t(KIDMP_NRATES) * prof : 0));
+    float *dio[12], *din[2];
+    for (int i = 0; i < 12; ++i) { dio[i] = d; d += prof; }
+    for (int i = 0; i < 2; ++i) { din[i] = d; d += prof; }
+    float *dppt = d; d += 4 * size_t(ncol);
+    int32_t *dnstep = nstep ? reinterpret_cast<int32_t *>(d) : nullptr;
+    hipStream_t s = ctx->stream;
+    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(dio[i], io[i], prof * sizeof(float), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < 2; ++i) HIPTRY(ctx, hipMemcpyAsync(din[i], in[i], prof * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPTRY(ctx, hipMemcpyAsync(dppt, ppt, 4 * size_t(ncol) * sizeof(float), hipMemcpyHostToDevice, s));
+    int rc = kidmp32_batch_step_device(ctx, ncol, nz, dt, dio[0], dio[1], dio[2], dio[3], dio[4], dio[5], dio[6], dio[7],
+                                       dio[8], dio[9], dio[10], dio[11], din[0], w, din[1], dppt, drates, dnstep, arith, s);
+    if (rc) return rc;
+    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(io[i], dio[i], prof * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPTRY(ctx, hipMemcpyAsync(ppt, dppt, 4 * size_t(ncol) * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (rates) HIPTRY(ctx, hipMemcpyAsync(rates, drates, size_t(KIDMP_NRATES) * prof * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (nstep) HIPTRY(ctx, hipMemcpyAsync(nstep, dnstep, 4 * size_t(ncol) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPTRY(ctx, hipStreamSynchronize(s));
+    return KIDMP_OK;
+}
+
+int kidmp32_column_step(kidmp_ctx *ctx, int32_t nz, float dt,
+                        float *qv1d, float *qc1d, float *qi1d, float *qr1d, float *qs1d, float *qg1d,
+                        float *ni1d, float *nr1d, float *nc1d, float *nwfa1d, float *nifa1d, float *t1d,
+                        const float *p1d, const float *w1d, const float *dzq, float *ppt, int32_t arith)
+{
+    return kidmp32_batch_step_host(ctx, 1, nz, dt, qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, nr1d, nc1d, nwfa1d,
+                                   nifa1d, t1d, p1d, w1d, dzq, ppt, nullptr, nullptr, arith);
 }
 
 int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n, const double *qv, const double *t, const double *p,
@@ -571,7 +656,7 @@ const char *kidmp_kernel_fingerprint(kidmp_ctx *ctx)
 {
     if (!ctx || !ctx->ready) return "";
     DeviceGuard guard_(ctx->cfg.device);
-    ctx->fingerprint = column_kernel_fingerprint(ctx->cfg.iiwarm != 0);
+    ctx->fingerprint = p64::column_kernel_fingerprint(ctx->cfg.iiwarm != 0);
     return ctx->fingerprint.c_str();
 }
 

@@ -12,27 +12,40 @@ namespace kidmp {
 constexpr int KIDMP_NRATES_ = 36;
 constexpr int MAX_CONST_SLOTS = 8;   // contexts alive at once per process (constant-memory slots)    // save_dg rates per level, order of M:2967-3119
 
-// All pointers are device pointers; profiles are x[col*nz + k] (k fastest).
-struct StepArgs {
-    double *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;   // INOUT, M:1168-1170
-    const double *p, *dz;                                                    // IN (w1d is inert, M:2797)
-    double *ppt;          // [ncol][4] rain, snow, graupel, ice (accumulated, M:1172)
-    double *rates;        // nullptr or [ncol][36][nz]
+// All pointers are device pointers; profiles are x[col*nz + k] (k fastest).  R = the reference's REAL in the
+// arithmetic variant that is launched: double (p64) or float (p32n, f32).
+template <class R>
+struct StepArgsT {
+    R *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;   // INOUT, M:1168-1170
+    const R *p, *dz;                                                    // IN (w1d is inert, M:2797)
+    R *ppt;               // [ncol][4] rain, snow, graupel, ice (accumulated, M:1172)
+    double *rates;        // nullptr or [ncol][36][nz] (binary64 in every variant: the rates are DOUBLE PRECISION)
     int32_t *nstep;       // nullptr or [ncol][4] rain, ice, snow, graupel
-    double *scratch;      // [ncol][nz] work profile owned by the context (block-K rain mvd, pass 1 -> pass 3)
+    R *scratch;           // [ncol][nz] work profile owned by the context (block-K rain mvd, pass 1 -> pass 3)
     int32_t cslot;        // slot of this context's Consts in constant memory (upload_consts)
     int32_t iiwarm;       // the context's iiwarm switch: selects the warm-rain instantiation of the kernel
     Tables tables;
     int64_t ncol;
     int32_t nz;
-    double dt;
-    int32_t debug_stop;   // 0 = run everything; n = leave after pass n-1 (profiling aid, env KIDMP_DEBUG_STOP)
+    R dt;
+    int32_t debug_stop;   // 0 = run everything; n = leave after pass n-1 (libkidmp_prof.so, env KIDMP_DEBUG_STOP)
 };
+typedef StepArgsT<double> StepArgs;
 
-hipError_t launch_column_step(const StepArgs &a, hipStream_t s);
-hipError_t upload_consts(int slot, const Consts &c);
+// thompson_column.hip is compiled once per arithmetic variant, each into its own namespace:
+//   p64  (real = double, dreal = double), p32n (float state, double rates: the reference as shipped), f32 (all float)
+#define KIDMP_DECLARE_VARIANT(ns, R)                                                        \
+    namespace ns {                                                                          \
+    hipError_t launch_column_step(const StepArgsT<R> &a, hipStream_t s);                    \
+    hipError_t upload_consts(int slot, const Consts &c);                                    \
+    std::string column_kernel_fingerprint(bool iiwarm);                                     \
+    }
+KIDMP_DECLARE_VARIANT(p64, double)
+KIDMP_DECLARE_VARIANT(p32n, float)
+KIDMP_DECLARE_VARIANT(f32, float)
+#undef KIDMP_DECLARE_VARIANT
+
 bool generated_consts_match(const Consts &c);   // thompson_consts_gen.h vs the run-time host init
 const char *column_kernel_name();
-std::string column_kernel_fingerprint(bool iiwarm);   // source hash + register/LDS/scratch use of the nz <= 120 kernel
 
 }  // namespace kidmp

@@ -11,9 +11,13 @@
 !     mp_thompson_batch(ncol, nz, dt, qv, ..., ppt)
 !
 ! Bodies are ISO_C_BINDING calls into libkidmp.so (include/kidmp.h), where the
-! column physics runs as hand-written HIP kernels on an MI355X.  State arrays
-! are copied to REAL(c_double) temporaries, so the module works whether KiD is
-! compiled with 4-byte or 8-byte default REAL (the computation is fp64).
+! column physics runs as hand-written HIP kernels on an MI355X.  Arithmetic (kidmp_arith):
+!   'p64'   (default) state arrays are copied to REAL(c_double) temporaries and the step runs in binary64 -- the
+!           parity build; works whether KiD is compiled with 4-byte or 8-byte default REAL;
+!   'p32n'  KiD's default 4-byte REAL only: the REAL arrays go to the GPU as they are and the kernel keeps the
+!           reference's own split -- what it declares REAL in binary32, its DOUBLE PRECISION rates in binary64
+!           (the reference as shipped);
+!   'f32'   likewise, everything binary32.
 !
 ! Like the reference it takes its switches from KiD's own modules:
 ! iiwarm, set_Nc (namelists, M:22), l_sediment (switches, M:20) and nx (parameters, M:23).
@@ -40,6 +44,7 @@ module module_mp_thompson09n
   logical, public :: is_aerosol_aware = .false.          ! M:28 (only .false. is supported)
   logical, public :: l_rate_diagnostics = .true.         ! replay the save_dg calls of M:2962-3124
   integer, public :: kidmp_device = 0                    ! HIP device ordinal of this process (one process per GPU)
+  character(4), public :: kidmp_arith = 'p64 '           ! 'p64', or with 4-byte default REAL 'p32n' / 'f32'
 
   ! the diagnosed rates in the reference's emission order (M:2967-3119): 30 mixed-phase, then 6 warm
   integer, parameter :: NRATES = 36, NRATES_MIXED = 30
@@ -86,6 +91,18 @@ module module_mp_thompson09n
        real(c_double), intent(in) :: p(*), w(*), dz(*)
        type(c_ptr), value :: rates, nstep            ! NULL, or [ncol][36][nz] doubles / [ncol][4] int32
      end function kidmp_batch_step_host_diag
+     integer(c_int) function kidmp32_batch_step_host(ctx, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, &
+          nc, nwfa, nifa, t, p, w, dz, ppt, rates, nstep, arith) bind(C, name='kidmp32_batch_step_host')
+       import :: c_int, c_int32_t, c_int64_t, c_float, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), value :: ncol
+       integer(c_int32_t), value :: nz, arith
+       real(c_float), value :: dt
+       real(c_float), intent(inout) :: qv(*), qc(*), qi(*), qr(*), qs(*), qg(*), ni(*), nr(*), &
+            nc(*), nwfa(*), nifa(*), t(*), ppt(*)
+       real(c_float), intent(in) :: p(*), w(*), dz(*)
+       type(c_ptr), value :: rates, nstep            ! NULL, or [ncol][36][nz] doubles / [ncol][4] int32
+     end function kidmp32_batch_step_host
   end interface
 
 contains
@@ -167,17 +184,43 @@ contains
     real, dimension(nz,ncol), intent(in) :: p, w, dz
     real, dimension(4,ncol), intent(inout) :: ppt
     real(c_double), allocatable, target :: s(:,:,:), f(:,:,:), pp(:,:), rates(:,:,:)
+    real(c_float), allocatable :: s4(:,:,:), f4(:,:,:), pp4(:,:)
     integer(c_int32_t), allocatable, target :: nstep(:,:)
     type(c_ptr) :: prates, pnstep
     integer(c_int) :: rc
+    integer(c_int32_t) :: arith
     integer :: i, k, r, r0
     if (.not. c_associated(ctx)) call thompson_init
-    allocate(s(nz,ncol,12), f(nz,ncol,3), pp(4,ncol))
     prates = c_null_ptr;  pnstep = c_null_ptr
     if (l_rate_diagnostics) then
        allocate(rates(nz,NRATES,ncol), nstep(4,ncol))       ! the C ABI's [ncol][36][nz] / [ncol][4]
        prates = c_loc(rates);  pnstep = c_loc(nstep)
     end if
+    if (trim(kidmp_arith) /= 'p64') then
+       ! ---- binary32 state straight to the GPU: the reference's own REAL / DOUBLE PRECISION split, or all binary32 ----
+       if (kind(qv) /= c_float) then
+          write(*,'(3a)') ' module_mp_thompson09n: kidmp_arith=', trim(kidmp_arith), ' needs KiD built with 4-byte default REAL'
+          stop 1
+       end if
+       arith = 0_c_int32_t
+       if (trim(kidmp_arith) == 'f32') arith = 1_c_int32_t
+       allocate(s4(nz,ncol,12), f4(nz,ncol,3), pp4(4,ncol))
+       s4(:,:,1) = qv;  s4(:,:,2) = qc;  s4(:,:,3) = qi;   s4(:,:,4) = qr
+       s4(:,:,5) = qs;  s4(:,:,6) = qg;  s4(:,:,7) = ni;   s4(:,:,8) = nr
+       s4(:,:,9) = nc;  s4(:,:,10) = nwfa; s4(:,:,11) = nifa; s4(:,:,12) = t
+       f4(:,:,1) = p;   f4(:,:,2) = w;   f4(:,:,3) = dz
+       pp4 = ppt
+       rc = kidmp32_batch_step_host(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_float), &
+            s4(:,:,1), s4(:,:,2), s4(:,:,3), s4(:,:,4), s4(:,:,5), s4(:,:,6), s4(:,:,7), s4(:,:,8), &
+            s4(:,:,9), s4(:,:,10), s4(:,:,11), s4(:,:,12), f4(:,:,1), f4(:,:,2), f4(:,:,3), pp4, prates, pnstep, arith)
+       call stop_on_error(rc, 'mp_thompson')
+       qv = s4(:,:,1);  qc = s4(:,:,2);  qi = s4(:,:,3);   qr = s4(:,:,4)
+       qs = s4(:,:,5);  qg = s4(:,:,6);  ni = s4(:,:,7);   nr = s4(:,:,8)
+       nc = s4(:,:,9);  nwfa = s4(:,:,10); nifa = s4(:,:,11); t = s4(:,:,12)
+       ppt = pp4
+       deallocate(s4, f4, pp4)
+    else
+    allocate(s(nz,ncol,12), f(nz,ncol,3), pp(4,ncol))
     s(:,:,1) = qv;  s(:,:,2) = qc;  s(:,:,3) = qi;   s(:,:,4) = qr
     s(:,:,5) = qs;  s(:,:,6) = qg;  s(:,:,7) = ni;   s(:,:,8) = nr
     s(:,:,9) = nc;  s(:,:,10) = nwfa; s(:,:,11) = nifa; s(:,:,12) = t
@@ -187,6 +230,12 @@ contains
          s(:,:,1), s(:,:,2), s(:,:,3), s(:,:,4), s(:,:,5), s(:,:,6), s(:,:,7), s(:,:,8), &
          s(:,:,9), s(:,:,10), s(:,:,11), s(:,:,12), f(:,:,1), f(:,:,2), f(:,:,3), pp, prates, pnstep)
     call stop_on_error(rc, 'mp_thompson')
+    qv = s(:,:,1);  qc = s(:,:,2);  qi = s(:,:,3);   qr = s(:,:,4)
+    qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7);   nr = s(:,:,8)
+    nc = s(:,:,9);  nwfa = s(:,:,10); nifa = s(:,:,11); t = s(:,:,12)
+    ppt = pp
+    deallocate(s, f, pp)
+    end if
     ! ---- the KiD block of M:2962-3124: per column, per level, 30 mixed-phase rates (.not. iiwarm) then 6 warm
     !      ones; save_dg(k, value, ...) when nx == 1, save_dg(k, ii, value, ...) otherwise; a column that left
     !      through the no_micro return (M:1540: all four substep counts 0) never reached the block ----
@@ -207,11 +256,6 @@ contains
        end do
        deallocate(rates, nstep)
     end if
-    qv = s(:,:,1);  qc = s(:,:,2);  qi = s(:,:,3);   qr = s(:,:,4)
-    qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7);   nr = s(:,:,8)
-    nc = s(:,:,9);  nwfa = s(:,:,10); nifa = s(:,:,11); t = s(:,:,12)
-    ppt = pp
-    deallocate(s, f, pp)
   end subroutine mp_thompson_batch
 
 end module module_mp_thompson09n

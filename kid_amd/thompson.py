@@ -75,6 +75,13 @@ def load_library(path=None):
     L.kidmp_batch_step_host.argtypes = [_vp, C.c_int64, C.c_int32, C.c_double] + [_dp] * 17
     L.kidmp_batch_step_device.restype = C.c_int
     L.kidmp_batch_step_device.argtypes = [_vp, C.c_int64, C.c_int32, C.c_double] + [_vp] * 18 + [_vp]
+    _fpp = C.POINTER(C.c_float)
+    L.kidmp32_batch_step_host.restype = C.c_int
+    L.kidmp32_batch_step_host.argtypes = [_vp, C.c_int64, C.c_int32, C.c_float] + [_fpp] * 16 + [_dp, C.POINTER(C.c_int32), C.c_int32]
+    L.kidmp32_batch_step_device.restype = C.c_int
+    L.kidmp32_batch_step_device.argtypes = [_vp, C.c_int64, C.c_int32, C.c_float] + [_vp] * 18 + [C.c_int32, _vp]
+    L.kidmp32_column_step.restype = C.c_int
+    L.kidmp32_column_step.argtypes = [_vp, C.c_int32, C.c_float] + [_fpp] * 16 + [C.c_int32]
     L.kidmp_default_aerosols_device.restype = C.c_int
     L.kidmp_default_aerosols_device.argtypes = [_vp, C.c_int64] + [_vp] * 6 + [_vp]
     L.kidmp_reduce_ppt_device.restype = C.c_int
@@ -206,6 +213,48 @@ class ThompsonMP:
                                                           rates.data_ptr() if rates is not None else None,
                                                           nstep.data_ptr() if nstep is not None else None]
         self._check(load_library().kidmp_batch_step_device(self._h, ncol, nz, float(dt), *args, s))
+
+    # ---- binary32 state: the reference's native arithmetic ("p32n": REAL = binary32, DOUBLE PRECISION = binary64)
+    #      and the all-binary32 build ("f32") -- include/kidmp.h, kidmp32_* ----
+    ARITH = {"p32n": 0, "f32": 1}
+
+    def batch_step32_host(self, st, dt, arith="p32n", ppt=None, want_rates=False, want_nstep=False):
+        """numpy float32 [ncol, nz] arrays, in place.  Returns (ppt float32 [ncol, 4], rates float64 or None, nstep or None)."""
+        ncol, nz = st["qv"].shape
+        fpp = C.POINTER(C.c_float)
+        for k in STATE_NAMES + FORCING_NAMES:
+            a = st[k]
+            if not (a.dtype == np.float32 and a.flags.c_contiguous and a.shape == (ncol, nz)):
+                raise KidmpError("batch_step32_host: %s must be contiguous float32 [ncol, nz]" % k)
+        if ppt is None:
+            ppt = np.zeros((ncol, 4), dtype=np.float32)
+        rates = np.zeros((ncol, NRATES, nz)) if want_rates else None
+        nstep = np.zeros((ncol, 4), dtype=np.int32) if want_nstep else None
+        self._check(load_library().kidmp32_batch_step_host(
+            self._h, ncol, nz, float(dt), *[st[k].ctypes.data_as(fpp) for k in STATE_NAMES + FORCING_NAMES],
+            ppt.ctypes.data_as(fpp), _np_ptr(rates) if want_rates else None,
+            nstep.ctypes.data_as(C.POINTER(C.c_int32)) if want_nstep else None, self.ARITH[arith]))
+        return ppt, rates, nstep
+
+    def batch_step32(self, st, dt, ppt, arith="p32n", rates=None, nstep=None, stream=None):
+        """torch float32 CUDA tensors [ncol, nz], in place, asynchronous (the device entry of the binary32 builds)."""
+        import torch
+        q = st["qv"]
+        ncol, nz = q.shape
+        for k in STATE_NAMES + ("p", "dz"):
+            self._want(st[k], torch.float32, (ncol, nz), "batch_step32: " + k)
+        self._want(ppt, torch.float32, (ncol, 4), "batch_step32: ppt")
+        if rates is not None:
+            self._want(rates, torch.float64, (ncol, NRATES, nz), "batch_step32: rates")
+        if nstep is not None:
+            self._want(nstep, torch.int32, (ncol, 4), "batch_step32: nstep")
+        s = stream if stream is not None else torch.cuda.current_stream(q.device).cuda_stream
+        w = st.get("w")
+        args = [st[k].data_ptr() for k in STATE_NAMES] + [st["p"].data_ptr(), w.data_ptr() if w is not None else None,
+                                                          st["dz"].data_ptr(), ppt.data_ptr(),
+                                                          rates.data_ptr() if rates is not None else None,
+                                                          nstep.data_ptr() if nstep is not None else None]
+        self._check(load_library().kidmp32_batch_step_device(self._h, ncol, nz, float(dt), *args, self.ARITH[arith], s))
 
     def default_aerosols(self, qv, t, p, stream=None):
         """nc, nwfa, nifa for the inputs the KiD wrapper leaves unset (W:36; formulas M:958-964)."""

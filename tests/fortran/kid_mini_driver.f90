@@ -1,12 +1,13 @@
 ! BASELINE config 1 through the Fortran boundary, driven exactly the way the KiD time loop drives a microphysics
 ! scheme -- call mphys_thompson09_interfacen, then state += dt * d(state)_mphys.
 !
-!   kid_mini_driver [nx [nsteps [case [dump_step]]]]
+!   kid_mini_driver [nx [nsteps [case [dump_step [arith]]]]]
 !     nx         replicated columns (default 1)
 !     nsteps     time steps (default 360)
 !     case       warm  = the KiD 1-D warm-rain case (KAT-B of SURVEY 9h: nz=120, dz=25 m, dt=10 s, zero forcing)
 !                mixed = the mixed-phase deep-convection sounding (KAT-A of SURVEY 9h, dz=125 m) fed through the wrapper
 !                dry   = the warm case without hydrometeors at 30 % of its vapour: mp_thompson returns at no_micro
+!     arith      p64 (default) | p32n | f32: module_mp_thompson09n's kidmp_arith (the last two need 4-byte default REAL)
 !     dump_step  write every save_dg call made during that step to dg_dump.txt (the recording `diagnostics` stub)
 ! Prints the end-state sums of column 1 and of column nx.
 program kid_mini_driver
@@ -15,7 +16,7 @@ program kid_mini_driver
   use namelists, only: iiwarm, set_Nc
   use diagnostics, only: recording, nlog, dump_log
   use mphys_thompson09n, only: mphys_thompson09_interfacen
-  use module_mp_thompson09n, only: thompson_finalize
+  use module_mp_thompson09n, only: thompson_finalize, kidmp_arith
   implicit none
   integer :: k, i, n, j, nsteps, dump_step
   real :: z, p, t, es, qsat
@@ -32,6 +33,7 @@ program kid_mini_driver
   if (command_argument_count() >= 4) then
      call get_command_argument(4, arg); read(arg,*) dump_step
   end if
+  if (command_argument_count() >= 5) call get_command_argument(5, kidmp_arith)   ! p64 (default) | p32n | f32
   iiwarm = trim(which) /= 'mixed'; set_Nc = 100.0
   call alloc_columns(nz, nx)
   do i = 1, nx

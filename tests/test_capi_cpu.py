@@ -59,7 +59,7 @@ def test_product_never_imports_the_oracle():
 
 def test_fortran_shim_binds_the_c_abi():
     src = open(os.path.join(ROOT, "kid_amd", "fortran", "module_mp_thompson09n.f90")).read()
-    for s in ("kidmp_init", "kidmp_finalize", "kidmp_batch_step_host", "kidmp_last_error"):
+    for s in ("kidmp_init", "kidmp_finalize", "kidmp_batch_step_host_diag", "kidmp_last_error"):
         assert "name='%s'" % s in src
     # the reference's dummy list, M:1156-1162
     assert re.search(r"subroutine mp_thompson \(qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, &\s*"

@@ -172,3 +172,29 @@ def test_no_micro_column_emits_no_rate_diagnostics(tmp_path):
     assert [e["form"] for e in log] == ["scalar"] * 5 and all(e["v"] == 0.0 for e in log)
     log, _ = _run_dump(tmp_path, 1, 2, "warm", 2)
     assert len(log) == 6 * 120 + 5
+
+
+def test_native_real4_kid_build_in_the_reference_native_arithmetic():
+    """KiD's default build (4-byte REAL) with kidmp_arith = 'p32n': the REAL arrays go to the GPU as they are and the
+    kernel keeps the reference's own REAL / DOUBLE PRECISION split.  The reference AS SHIPPED ends this case at
+    sum(qc) 2.218541e-2, sum(qr) 2.693803e-3, sum(nr) 1.060634e6 (native); its P64 build elsewhere."""
+    exe32 = os.path.join(ROOT, "kid_amd", "fortran", "build32", "kid_mini_driver")
+    if not os.path.exists(exe32):
+        pytest.skip("build32 not built (make -C kid_amd/fortran FFLAGS=-O2 B=build32)")
+    res = {}
+    for arith in ("p32n", "f32"):
+        out = subprocess.run([exe32, "1", "360", "warm", "0", arith], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        for line in out.stdout.splitlines():
+            p = line.split()
+            if p and p[0] == "KATB":
+                res[arith] = np.array([float(x) for x in p[1:5]])
+    native = np.array([1.530434, 2.218541e-2, 2.693803e-3, 1.060634e6])
+    p64 = np.array([1.530434, 2.218719e-2, 2.694135e-3, 1.060568e6])
+    print("KAT-B through the Fortran drop-in:", res)
+    assert np.all(np.abs(res["p32n"] / native - 1) < 4e-5), res["p32n"]
+    assert np.all(np.abs(res["p32n"][1:] - native[1:]) < 0.5 * np.abs(p64[1:] - native[1:])), res["p32n"]
+    assert np.all(np.abs(res["f32"] / native - 1) < 3e-4), res["f32"]
+    # the 8-byte build refuses the binary32 arithmetic instead of converting silently
+    out = subprocess.run([EXE, "1", "2", "warm", "0", "p32n"], capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "4-byte default REAL" in out.stdout + out.stderr
