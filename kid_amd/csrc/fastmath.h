@@ -128,6 +128,38 @@ KFM_FN double cbrt_pos(double x)
     return std::fma(r, t * (1. / 3.), c);
 }
 
+// a / b for finite, normal b and a/b well inside the exponent range: v_rcp_f64 seed, Newton steps, one residual
+// correction of the quotient (the compiler's own `afn` expansion does two Newton steps; KFM_DIV_NR selects).
+#ifndef KFM_DIV_NR
+#define KFM_DIV_NR 1
+#endif
+KFM_FN double div(double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(b);
+#else
+    double y = double(1.0f / float(b));
+#endif
+    y = std::fma(std::fma(-b, y, 1.0), y, y);
+#if KFM_DIV_NR >= 2
+    y = std::fma(std::fma(-b, y, 1.0), y, y);
+#endif
+    const double q = a * y;
+    return std::fma(std::fma(-b, q, a), y, q);
+}
+
+// 1 / b: seed + two Newton steps (<= 1 ulp)
+KFM_FN double rcp(double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(b);
+#else
+    double y = double(1.0f / float(b));
+#endif
+    y = std::fma(std::fma(-b, y, 1.0), y, y);
+    return std::fma(std::fma(-b, y, 1.0), y, y);
+}
+
 // ---- the libm entry points the scheme uses, on positive finite normal x / moderate arguments ----
 KFM_FN double log(double x)
 {
