@@ -89,8 +89,8 @@ KFM_FN double exp_small(double r)
 }
 
 // sqrt(x) for positive, finite, normal x well inside the exponent range (no rescaling, no 0/inf cases):
-// reciprocal-square-root seed, one Goldschmidt step and two residual corrections (the iteration the compiler's
-// own fp64 sqrt expansion uses, minus its range handling).  <= 1 ulp.
+// reciprocal-square-root seed, one Goldschmidt step and one residual correction (the iteration the compiler's
+// own fp64 sqrt expansion uses, minus its range handling and its second correction).  <= 1 ulp.
 KFM_FN double sqrt_pos(double x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -102,9 +102,7 @@ KFM_FN double sqrt_pos(double x)
     const double r0 = std::fma(-h0, g0, 0.5);
     const double g1 = std::fma(g0, r0, g0), h1 = std::fma(h0, r0, h0);
     const double d0 = std::fma(-g1, g1, x);
-    const double g2 = std::fma(d0, h1, g1);
-    const double d1 = std::fma(-g2, g2, x);
-    return std::fma(d1, h1, g2);
+    return std::fma(d0, h1, g1);                         // g1 is good to ~2**-47 (seed 2**-24): one residual correction suffices
 }
 
 // cbrt(x) for positive x in [1e-37, 1e37] (the fp32 range: the seed is taken in fp32):
