@@ -167,6 +167,14 @@ int kidmp_sanity_device(kidmp_ctx *ctx, int64_t n, const double *qc, const doubl
                         const double *qs, const double *qi, const double *qg, const double *ni, const double *qv,
                         double *out15, void *stream);
 
+/* calc_effectRad (M:4834-4935): radiation effective radii of cloud water, cloud ice and snow, consistent with the
+ * scheme's size distributions.  n = ncol*nz elements, device pointers; re_qc/re_qi/re_qs are INOUT like the reference's
+ * (a level without the species keeps the caller's value; the scheme's 3-D driver presets 2.49E-6, 4.99E-6, 9.99E-6 m
+ * and clamps afterwards, M:1111-1121). */
+int kidmp_effective_radii_device(kidmp_ctx *ctx, int64_t n, const double *t, const double *p, const double *qv,
+                                 const double *qc, const double *nc, const double *qi, const double *ni,
+                                 const double *qs, double *re_qc, double *re_qi, double *re_qs, void *stream);
+
 /* Introspection for parity tests: copy a lookup table / constant array to the
  * host.  Names are the reference's (tcg_racg ... t_Efsw; cre, crg, Dr ...).
  * Returns the number of doubles (<0 on error); out may be NULL to query. */

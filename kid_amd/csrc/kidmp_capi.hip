@@ -201,6 +201,49 @@ __global__ void k_sanity_final(const unsigned long long *acc, double *out15)
     else if (i < 15) out15[i] = double(acc[i]);
 }
 
+// calc_effectRad, M:4834-4935: effective radii of cloud water, cloud ice and snow for radiation coupling.  Pointwise in
+// (column, level); re_* are INOUT (a level without the species keeps the caller's value, M:4873/4888/4897).  The
+// reference's column-wide has_qc/has_qi/has_qs flags only skip loops whose bodies test the level again.
+struct RadConsts { double Nt_c, cig2, oig1, oams, cse1, sa[10], sb[10]; };
+__global__ void k_effective_radii(int64_t n, RadConsts c, const double *__restrict__ t, const double *__restrict__ p,
+                                  const double *__restrict__ qv, const double *__restrict__ qc, const double *__restrict__ nc1,
+                                  const double *__restrict__ qi, const double *__restrict__ ni1, const double *__restrict__ qs,
+                                  double *__restrict__ re_qc, double *__restrict__ re_qi, double *__restrict__ re_qs)
+{
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double am_r_ = PI * rho_w / 6.0, am_i_ = PI * rho_i / 6.0;
+    const double rho = 0.622 * p[i] / (Rgas * t[i] * (qv[i] + 0.622));
+    const double rc = fmax(R1, qc[i] * rho);
+    double nc = fmax(R2, nc1[i] * rho);
+    nc = c.Nt_c;                                                        // .NOT. is_aerosol_aware, M:4863
+    const double ri = fmax(R1, qi[i] * rho), ni = fmax(R2, ni1[i] * rho), rs = fmax(R1, qs[i] * rho);
+    if (!(rc <= R1 || nc <= R2)) {                                      // M:4873-4884
+        int inu_c;
+        if (nc < 100.) inu_c = 15;
+        else if (nc > 1.E10) inu_c = 2;
+        else { inu_c = int(lround(1000.E6 / nc)) + 2; inu_c = inu_c < 15 ? inu_c : 15; }
+        const double g_ratio = double((inu_c + 1) * (inu_c + 2) * (inu_c + 3));   // 24, 60, 120 ... 4896 = (n+1)(n+2)(n+3)
+        const double lamc = fm::cbrt_pos(nc * am_r_ * g_ratio / rc);
+        re_qc[i] = fmax(2.51E-6, fmin(0.5 * double(3. + inu_c) / lamc, 50.E-6));
+    }
+    if (!(ri <= R1 || ni <= R2)) {                                      // M:4887-4893
+        const double lami = fm::cbrt_pos(am_i_ * c.cig2 * c.oig1 * ni / ri);
+        re_qi[i] = fmax(5.01E-6, fmin(0.5 * double(3. + mu_i) / lami, 125.E-6));
+    }
+    if (!(rs <= R1)) {                                                  // M:4896-4930 (bm_s = 2: smo2 = smob)
+        const double tc0 = fmin(-0.1, t[i] - 273.15), x = c.cse1;
+        const double smob = rs * c.oams;
+        const double *a = c.sa, *b = c.sb;
+        const double loga_ = a[0] + a[1] * tc0 + a[2] * x + a[3] * tc0 * x + a[4] * tc0 * tc0 + a[5] * x * x
+                           + a[6] * tc0 * tc0 * x + a[7] * tc0 * x * x + a[8] * tc0 * tc0 * tc0 + a[9] * x * x * x;
+        const double b_ = b[0] + b[1] * tc0 + b[2] * x + b[3] * tc0 * x + b[4] * tc0 * tc0 + b[5] * x * x
+                        + b[6] * tc0 * tc0 * x + b[7] * tc0 * x * x + b[8] * tc0 * tc0 * tc0 + b[9] * x * x * x;
+        const double smoc = fm::pow10_times_pow(loga_, fm::log2_parts(smob), b_);
+        re_qs[i] = fmax(10.E-6, fmin(0.5 * (smoc / smob), 999.E-6));
+    }
+}
+
 struct Named { const char *name; const double *ptr; int64_t n; };
 
 std::vector<Named> table_dir(const Tables &t)
@@ -651,6 +694,27 @@ int kidmp_sanity_device(kidmp_ctx *ctx, int64_t n, const double *qc, const doubl
         hipLaunchKernelGGL(k_sanity, dim3((unsigned)g), dim3(T), 0, s, n, p, ctx->d_sanity);
     }
     hipLaunchKernelGGL(k_sanity_final, dim3(1), dim3(64), 0, s, ctx->d_sanity, out15);
+    HIPTRY(ctx, hipGetLastError());
+    return KIDMP_OK;
+}
+
+int kidmp_effective_radii_device(kidmp_ctx *ctx, int64_t n, const double *t, const double *p, const double *qv,
+                                 const double *qc, const double *nc, const double *qi, const double *ni, const double *qs,
+                                 double *re_qc, double *re_qi, double *re_qs, void *stream)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (n < 0 || !t || !p || !qv || !qc || !nc || !qi || !ni || !qs || !re_qc || !re_qi || !re_qs)
+        return fail(ctx, KIDMP_EINVAL, "kidmp_effective_radii_device: bad argument");
+    if (n == 0) return KIDMP_OK;
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, t, "t")) return rc;
+    if (int rc = check_on_device(ctx, re_qc, "re_qc")) return rc;
+    RadConsts c{};
+    c.Nt_c = ctx->hc.Nt_c; c.cig2 = ctx->hc.cig[1]; c.oig1 = ctx->hc.oig1; c.oams = ctx->hc.oams; c.cse1 = ctx->hc.cse[0];
+    for (int i = 0; i < 10; ++i) { c.sa[i] = ctx->hc.sa[i]; c.sb[i] = ctx->hc.sb[i]; }
+    const int T = 256;
+    hipLaunchKernelGGL(k_effective_radii, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, (hipStream_t)stream, n, c,
+                       t, p, qv, qc, nc, qi, ni, qs, re_qc, re_qi, re_qs);
     HIPTRY(ctx, hipGetLastError());
     return KIDMP_OK;
 }

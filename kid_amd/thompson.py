@@ -90,6 +90,8 @@ def load_library(path=None):
     L.kidmp_reduce_rates_device.argtypes = [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]
     L.kidmp_sanity_device.restype = C.c_int
     L.kidmp_sanity_device.argtypes = [_vp, C.c_int64] + [_vp] * 9 + [_vp]
+    L.kidmp_effective_radii_device.restype = C.c_int
+    L.kidmp_effective_radii_device.argtypes = [_vp, C.c_int64] + [_vp] * 11 + [_vp]
     L.kidmp_kernel_fingerprint.restype = C.c_char_p
     L.kidmp_kernel_fingerprint.argtypes = [_vp]
     L.kidmp_reserve.restype = C.c_int
@@ -307,6 +309,20 @@ class ThompsonMP:
         self._check(load_library().kidmp_sanity_device(self._h, q.numel(), *[st[k].data_ptr() for k in self.SANITY_NEG],
                                                        out.data_ptr(), s))
         return out
+
+    def effective_radii(self, st, preset=(2.49e-6, 4.99e-6, 9.99e-6), stream=None):
+        """calc_effectRad (M:4834-4935): (re_qc, re_qi, re_qs) [ncol, nz] on the device, started from the presets of the
+        scheme's driver (M:1111-1113)."""
+        import torch
+        q = st["qv"]
+        for k in ("t", "p", "qv", "qc", "nc", "qi", "ni", "qs"):
+            self._want(st[k], torch.float64, tuple(q.shape), "effective_radii: " + k)
+        out = [torch.full_like(q, v) for v in preset]
+        s = stream if stream is not None else torch.cuda.current_stream(q.device).cuda_stream
+        self._check(load_library().kidmp_effective_radii_device(
+            self._h, q.numel(), *[st[k].data_ptr() for k in ("t", "p", "qv", "qc", "nc", "qi", "ni", "qs")],
+            *[o.data_ptr() for o in out], s))
+        return tuple(out)
 
     def kernel_fingerprint(self):
         """'src:<hash>;vgpr:<n>;lds:<bytes>;scratch:<bytes>' of this context's nz <= 120 column-step kernel."""

@@ -48,6 +48,7 @@ def lib():
         L.th_oracle_create.restype = C.c_void_p
         L.th_oracle_create.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p]
         L.th_oracle_destroy.argtypes = [C.c_void_p]
+        L.th_oracle_set_aerosol_aware.argtypes = [C.c_void_p, C.c_int]
         L.th_oracle_mp_thompson.restype = C.c_int
         L.th_oracle_mp_thompson.argtypes = [C.c_void_p] + [_dp] * 16 + [
             C.c_int, C.c_double, _dp, C.POINTER(C.c_int)]
@@ -71,6 +72,8 @@ def lib():
         for f in ("th_oracle_view_const", "th_oracle_view_const_p32n"):
             getattr(L, f).restype = C.c_double
             getattr(L, f).argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.th_oracle_calc_effectRad.restype = None
+        L.th_oracle_calc_effectRad.argtypes = [C.c_void_p, C.c_int] + [_dp] * 11
         L.th_oracle_default_aerosols.argtypes = [C.c_void_p, C.c_int] + [_dp] * 6
         L.th_oracle_kid_interface.restype = C.c_int
         L.th_oracle_kid_interface.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double,
@@ -101,7 +104,7 @@ FORCING = ("p", "w", "dz")
 class Oracle:
     """thompson_init + mp_thompson of the reference, restated on the CPU."""
 
-    def __init__(self, iiwarm=False, set_Nc=100.0, l_sediment=True, nthreads=None, cache=True):
+    def __init__(self, iiwarm=False, set_Nc=100.0, l_sediment=True, nthreads=None, cache=True, aerosol_aware=False):
         nthreads = nthreads or min(os.cpu_count() or 1, 16)
         path = None
         if cache and not iiwarm:
@@ -112,6 +115,12 @@ class Oracle:
         self._h = lib().th_oracle_create(int(iiwarm), float(set_Nc), int(l_sediment), nthreads, path)
         if not self._h:
             raise MemoryError("th_oracle_create failed")
+        if aerosol_aware:
+            self.set_aerosol_aware(True)
+
+    def set_aerosol_aware(self, flag):
+        """is_aerosol_aware of M:28 (call between steps only)."""
+        lib().th_oracle_set_aerosol_aware(self._h, int(bool(flag)))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -197,6 +206,18 @@ class Oracle:
     def view_const(self, name, idx=0, p32n=False):
         f = lib().th_oracle_view_const_p32n if p32n else lib().th_oracle_view_const
         return f(self._h, name.encode(), int(idx))
+
+    def calc_effectRad(self, st, preset=(2.49e-6, 4.99e-6, 9.99e-6)):
+        """calc_effectRad (M:4834-4935) on [ncol, nz] or [nz] arrays; returns (re_qc, re_qi, re_qs) started from the
+        driver's presets (M:1111-1113)."""
+        shp = st["qv"].shape
+        nz = shp[-1]
+        a = {k: np.ascontiguousarray(st[k].reshape(-1, nz)) for k in ("t", "p", "qv", "qc", "nc", "qi", "ni", "qs")}
+        out = [np.full_like(a["t"], v) for v in preset]
+        for i in range(a["t"].shape[0]):
+            lib().th_oracle_calc_effectRad(self._h, nz, *[_p(a[k][i]) for k in ("t", "p", "qv", "qc", "nc", "qi", "ni", "qs")],
+                                           *[_p(o[i]) for o in out])
+        return tuple(o.reshape(shp) for o in out)
 
     def default_aerosols(self, qv, t, p):
         nz = qv.shape[-1]

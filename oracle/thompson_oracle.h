@@ -43,6 +43,10 @@ typedef struct th_oracle th_oracle;
 th_oracle *th_oracle_create(int iiwarm, double set_Nc, int l_sediment,
                             int nthreads, const char *cache_path);
 void th_oracle_destroy(th_oracle *o);
+/* is_aerosol_aware (M:28; .false. in KiD and by default here): .true. switches on the aerosol-aware branch --
+ * prognostic droplet number, activ_ncloud, iceDeMott, iceKoop, aerosol scavenging tendencies, droplet evaporation
+ * from tnc_wev (M:1410, M:2043-2111, M:2397-2408, M:2602, M:2796-2852, M:2867).  Not thread-safe against running steps. */
+void th_oracle_set_aerosol_aware(th_oracle *o, int flag);
 
 /* mp_thompson (M:1156-3688): one column, one step.  Arrays hold levels
  * kts..kte as C index 0..nz-1.  ppt = {pptrain, pptsnow, pptgraul, pptice}
@@ -137,6 +141,13 @@ int th_oracle_kid_interface_p32n(const th_oracle *o, int nz, int nx, float dt, f
 /* the constants mp_thompson reads in each arithmetic, by name (tests): -1e30 if unknown */
 double th_oracle_view_const(const th_oracle *o, const char *name, int idx);
 double th_oracle_view_const_p32n(const th_oracle *o, const char *name, int idx);
+
+/* calc_effectRad (M:4834-4935): effective radii of cloud water / cloud ice / snow for radiation coupling; re_* are
+ * INOUT (levels without the species keep the caller's value). */
+void th_oracle_calc_effectRad(const th_oracle *o, int nz,
+                              const double *t1d, const double *p1d, const double *qv1d, const double *qc1d,
+                              const double *nc1d, const double *qi1d, const double *ni1d, const double *qs1d,
+                              double *re_qc1d, double *re_qi1d, double *re_qs1d);
 
 /* Non-aerosol defaults for the inputs the KiD wrapper leaves unset
  * (decision U2 of SURVEY 8c; formulas of M:958-964). */

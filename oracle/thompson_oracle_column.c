@@ -122,6 +122,60 @@ static inline real mom_b(const real *sb, real tc0, real x)
          + sb[9] * tc0 * tc0 * tc0 + sb[10] * x * x * x;
 }
 
+/* ---- aerosol-aware branch (is_aerosol_aware = .true.) ---- */
+/* iceDeMott M:4720-4759 (DeMott et al. 2010 dust deposition/condensation nucleation) */
+static real iceDeMott(real tempc, real qv_, real qvs_, real qvsi_, real rho_, real nifa_)
+{
+    (void)qv_; (void)qvs_; (void)qvsi_;
+    const real rho_not0 = 101325. / (287.05 * 273.15);
+    real nifa_cc = nifa_ * rho_not0 * 1.E-6 / rho_;
+    real xni = (5.94e-5 * pow(-tempc, (real)3.33)) * pow(nifa_cc, ((-0.0264 * (tempc)) + 0.0033));
+    xni = xni * rho_ / rho_not0 * 1000.;
+    return MAXD((real)0., xni);
+}
+/* iceKoop M:4767-4793 (homogeneous freezing of aqueous aerosols, Koop et al. 2001, rate reduced) */
+static real iceKoop(real temp_, real qv_, real qvs_, real naero, real DT_)
+{
+    const real R_uni = 8.314, ar_volume = 4. / 3. * PI * ((real)2.5e-6 * (real)2.5e-6 * (real)2.5e-6);   /* M:155,162: (2.5e-6)**3 */
+    real xni = 0.0;
+    real satw_ = qv_ / qvs_;
+    real mu_diff = 210368.0 + (131.438 * temp_) - (3.32373E6 / temp_) - (41729.1 * log(temp_));
+    real a_w_i = exp(mu_diff / (R_uni * temp_));
+    real delta_aw = satw_ - a_w_i;
+    real log_J_rate = -906.7 + (8502.0 * delta_aw) - (26924.0 * delta_aw * delta_aw) + (29180.0 * delta_aw * delta_aw * delta_aw);
+    log_J_rate = MIND((real)20.0, log_J_rate);
+    real J_rate = pow((real)10., log_J_rate);
+    real prob_h = MIND(1. - exp(-J_rate * ar_volume * DT_), (real)1.);
+    if (prob_h > 0.) xni = MIND(prob_h * naero, (real)1000.E3);
+    return MAXD((real)0.0, xni);
+}
+/* activ_ncloud M:4451-4526.  tnccn_act is 1.0 everywhere in this fork (M:752-762: the CCN activation file of the
+ * MPAS original is not read), so the bilinear interpolation runs on a table of ones. */
+static real activ_ncloud(real Tt, real Ww, real NCCN)
+{
+    static const real ta_Na[8] = { 0, 10.0, 31.6, 100.0, 316.0, 1000.0, 3160.0, 10000.0 };                 /* ntb_arc = 7 */
+    static const real ta_Ww[10] = { 0, 0.01, 0.0316, 0.1, 0.316, 1.0, 3.16, 10.0, 31.6, 100.0 };           /* ntb_arw = 9 */
+    const int ntb_arc = 7, ntb_arw = 9;
+    real n_local = NCCN * 1.E-6, w_local = Ww;
+    int n, i, j;
+    (void)Tt;                                                    /* k = table temperature index: every entry is 1.0 */
+    if (n_local >= ta_Na[ntb_arc]) n_local = ta_Na[ntb_arc] - 1.0;
+    else if (n_local <= ta_Na[1]) n_local = ta_Na[1] + 1.0;
+    for (n = 2; n <= ntb_arc; n++) if (n_local >= ta_Na[n - 1] && n_local < ta_Na[n]) break;
+    i = n;
+    real x1 = log(ta_Na[i - 1]), x2 = log(ta_Na[i]);
+    if (w_local >= ta_Ww[ntb_arw]) w_local = ta_Ww[ntb_arw] - 1.0;
+    else if (w_local <= ta_Ww[1]) w_local = ta_Ww[1] + 0.001;
+    for (n = 2; n <= ntb_arw; n++) if (w_local >= ta_Ww[n - 1] && w_local < ta_Ww[n]) break;
+    j = n;
+    real y1 = log(ta_Ww[j - 1]), y2 = log(ta_Ww[j]);
+    const real A = 1.0, B = 1.0, C = 1.0, D = 1.0;               /* tnccn_act(i-1..i, j-1..j, k, 3, 2) */
+    real nx = log(n_local), wy = log(w_local);
+    real t = (nx - x1) / (x2 - x1), u = (wy - y1) / (y2 - y1);
+    real fraction = (1.0 - t) * (1.0 - u) * A + t * (1.0 - u) * B + t * u * C + (1.0 - t) * u * D;
+    return NCCN * fraction;
+}
+
 /* "first of {nic-1,nic,nic+1} whose mantissa is in [1,10), else nic+1";
  * idx = INT(x/10**n) + 10*(n-n0) - (n-n0), clamped.  M:1763-1771 and its
  * seven siblings. */
@@ -147,8 +201,9 @@ DECADE_INDEX(decade_index_d, double)   /* DOUBLE N0_exp: DLOG10, N0_exp/10.**n w
  * REAL exp, M:4598-4651); the DOUBLE PRECISION bins and the R8 lookup tables are shared with the context.  In the
  * P64 build the values equal the context's own, bit for bit (tests/test_oracle_p32n.py checks that). */
 typedef struct {
-    int iiwarm, l_sediment;
+    int iiwarm, l_sediment, is_aerosol_aware;
     real Nt_c, Sc3, D0i, xm0s, xm0g;
+    const double *tnc_wev, *t_Nc; int nic1;
     real sa[11], sb[11];
     real r_c[ntb_c + 1], r_i[ntb_i + 1], r_r[ntb_r + 1], r_g[ntb_g + 1], r_s[ntb_s + 1], Nt_i[ntb_i1 + 1];
     real cce[6][16], ccg[6][16], ocg1[16], ocg2[16];
@@ -186,7 +241,8 @@ void *P(th_oracle_make_view)(const th_oracle *c)
 {
     th_view *o = (th_view *)calloc(1, sizeof *o);
     if (!o) return NULL;
-    o->iiwarm = c->iiwarm; o->l_sediment = c->l_sediment;
+    o->iiwarm = c->iiwarm; o->l_sediment = c->l_sediment; o->is_aerosol_aware = c->is_aerosol_aware;
+    o->tnc_wev = c->tnc_wev; o->t_Nc = c->t_Nc; o->nic1 = c->nic1;
     o->Nt_c = (real)c->set_Nc * 1.e6;                               /* M:381 */
     for (int i = 1; i <= 10; i++) { o->sa[i] = (real)c->sa[i]; o->sb[i] = (real)c->sb[i]; }   /* REAL PARAMETERs: nearest to the text */
     for (int i = 1; i <= ntb_c; i++) o->r_c[i] = (real)c->r_c[i];
@@ -380,7 +436,7 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
                                 int nz, real dt, double *rates, int *nstep_out, int *illcond, int force)
 {
     const th_view *o = (const th_view *)ctx->P(view);
-    (void)w1d;   /* only read by activ_ncloud (aerosol-aware, M:2797) */
+    const int aero = o->is_aerosol_aware;                      /* M:28; .false. in KiD, settable here */
     const int kts = 0, kte = nz - 1;
     const size_t NA = 100, ND = 80;
     real *ws = (real *)calloc(NA * (size_t)(nz + 2), sizeof(real));          /* REAL work arrays */
@@ -489,7 +545,7 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
             else if (xDc > D0r * 2.)
                 lamc = cce2[nu_c] / (D0r * 2.);
             nc[k] = MIND(Nt_c_max, ccg1[nu_c] * ocg2[nu_c] * rc[k] / am_r * pow(lamc, bm_r));
-            nc[k] = Nt_c;                                    /* M:1410, .NOT. is_aerosol_aware */
+            if (!aero) nc[k] = Nt_c;                         /* M:1410 */
         } else {
             qc1d[k] = 0.0;
             nc1d[k] = 0.0;
@@ -921,15 +977,23 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
                     pni_wfz[k] = nc[k] * odts;
                 }
 
-                /* Cooper nucleation M:2090-2101 */
+                /* Cooper nucleation, or DeMott's dust nucleation when aerosol-aware (dustyIce = .true., M:30), M:2090-2101 */
                 if ((ssati[k] >= 0.25) || (ssatw[k] > eps && temp[k] < 253.15)) {
-                    xnc = MIND(250.E3, TNO * exp(ATO * (T_0 - temp[k])));
+                    if (aero) xnc = iceDeMott(tempc, qv[k], qvs[k], qvsi[k], rho[k], nifa[k]);
+                    else      xnc = MIND(250.E3, TNO * exp(ATO * (T_0 - temp[k])));
                     xni = ni[k] + (pni_rfz[k] + pni_wfz[k]) * dtsave;
                     pni_inu[k] = 0.5 * (xnc - xni + fabs(xnc - xni)) * odts;
                     pri_inu[k] = MIND(rate_max, xm0i * pni_inu[k]);
                     pni_inu[k] = pri_inu[k] / xm0i;
                 }
-                /* Koop freezing M:2104-2111 needs is_aerosol_aware: unreachable */
+                /* freezing of aqueous aerosols, Koop et al. (2001), M:2103-2111 (homogIce = .true., M:31) */
+                xni = smo0[k] + ni[k] + (pni_rfz[k] + pni_wfz[k] + pni_inu[k]) * dtsave;
+                if (aero && (xni <= 500.E3) && (temp[k] < 238) && (ssati[k] >= 0.4)) {
+                    xnc = iceKoop(temp[k], qv[k], qvs[k], nwfa[k], dtsave);
+                    pni_iha[k] = xnc * odts;
+                    pri_iha[k] = MIND(rate_max, xm0i * 0.1 * pni_iha[k]);
+                    pni_iha[k] = pri_iha[k] / (xm0i * 0.1);
+                }
 
                 /* ice deposition/sublimation M:2116-2149 */
                 if (L_qi[k]) {
@@ -1152,6 +1216,12 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
         orho = 1. / rho[k];
         lfus2 = lsub - lvap[k];
 
+        if (aero) {                                          /* M:2397-2408 (dustyIce = .true.) */
+            nwfaten[k] = nwfaten[k] - (pna_rca[k] + pna_sca[k] + pna_gca[k] + pni_iha[k]) * orho;
+            nifaten[k] = nifaten[k] - (pnd_rcd[k] + pnd_scd[k] + pnd_gcd[k]) * orho;
+            nifaten[k] = nifaten[k] - pni_inu[k] * orho;
+        }
+
         qvten[k] = qvten[k] + (-pri_inu[k] - pri_iha[k] - pri_ide[k] - prs_ide[k] - prs_sde[k] - prg_gde[k]) * orho;
 
         qcten[k] = qcten[k] + (-prr_wau[k] - pri_wfz[k] - prr_rcw[k] - prs_scw[k] - prg_scw[k] - prg_gcw[k]) * orho;
@@ -1283,7 +1353,7 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
         if ((qc1d[k] + qcten[k] * DT) > R1) {
             rc[k] = (qc1d[k] + qcten[k] * DT) * rho[k];
             nc[k] = MAXD(2., (nc1d[k] + ncten[k] * DT) * rho[k]);
-            nc[k] = Nt_c;
+            if (!aero) nc[k] = Nt_c;                         /* M:2602 */
             L_qc[k] = 1;
         } else {
             rc[k] = R1;
@@ -1407,10 +1477,33 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
             if (xrc > R1) {
                 prw_vcd[k] = clap * odt;
                 if (clap > eps) {
-                    xnc = Nt_c;
+                    if (aero) xnc = MAXD((real)2., activ_ncloud(temp[k], w1d[k], nwfa[k]));   /* M:2796-2797 */
+                    else      xnc = Nt_c;
                     pnc_wcd[k] = 0.5 * (xnc - nc[k] + fabs(xnc - nc[k])) * odts * orho;
+                } else if (clap < -eps && ssatw[k] < -1.E-6 && aero) {      /* droplet evaporation, M:2804-2852 */
+                    tempc = temp[k] - 273.15;
+                    otemp = 1. / temp[k];
+                    rvs = rho[k] * qvs[k];
+                    rvs_p = rvs * otemp * (lvap[k] * otemp * oRv - 1.);
+                    rvs_pp = rvs * (otemp * (lvap[k] * otemp * oRv - 1.) * otemp * (lvap[k] * otemp * oRv - 1.)
+                                    + (-2. * lvap[k] * otemp * otemp * otemp * oRv) + otemp * otemp);
+                    gamsc = lvap[k] * diffu[k] / tcond[k] * rvs_p;
+                    alphsc = 0.5 * (gamsc / (1. + gamsc)) * (gamsc / (1. + gamsc)) * rvs_pp / rvs_p * rvs / rvs_p;
+                    alphsc = MAXD(1.E-9, alphsc);
+                    xsat = ssatw[k];
+                    if (fabs(xsat) < 1.E-9) xsat = 0.;
+                    t1_evap = 2. * PI * (1.0 - alphsc * xsat + 2. * alphsc * alphsc * xsat * xsat
+                                         - 5. * alphsc * alphsc * alphsc * xsat * xsat * xsat) / (1. + gamsc);
+                    double Dc_star = sqrt((double)-2. * DT * t1_evap / (2. * PI) * 4. * diffu[k] * ssatw[k] * rvs / rho_w);
+                    int idx_d = clampi((int)(1.E6 * Dc_star), 1, nbc);
+                    int idx_n = NINT(1.0 + (real)nbc * log(nc[k] / o->t_Nc[1]) / o->nic1);
+                    idx_n = clampi(idx_n, 1, nbc);
+                    if (rc[k] > o->r_c[1]) idx_c = decade_index(rc[k], NINT(log10(rc[k])), o->nic2, ntb_c);
+                    else idx_c = 1;
+                    prw_vcd[k] = MAXD((double)(-rc[k] * 0.99 * orho * odt), prw_vcd[k]);
+                    pnc_wcd[k] = MAXD((double)(-nc[k] * 0.99 * orho * odt),
+                                      (double)(-o->tnc_wev[IX3(idx_d, idx_c, idx_n, nbc, ntb_c)] * orho * odt));
                 }
-                /* evaporation branch M:2804-2852 needs is_aerosol_aware */
             } else {
                 prw_vcd[k] = -rc[k] * orho * odt;
                 pnc_wcd[k] = -nc[k] * orho * odt;
@@ -1423,7 +1516,7 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
             tten[k] = tten[k] + lvap[k] * ocp[k] * prw_vcd[k] * (1 - IFDRY);
             rc[k] = MAXD(R1, (qc1d[k] + DT * qcten[k]) * rho[k]);
             nc[k] = MAXD(2., (nc1d[k] + DT * ncten[k]) * rho[k]);
-            nc[k] = Nt_c;
+            if (!aero) nc[k] = Nt_c;                         /* M:2867 */
             qv[k] = MAXD(1.E-10, qv1d[k] + DT * qvten[k]);
             temp[k] = t1d[k] + DT * tten[k];
             rho[k] = 0.622 * pres[k] / (R_gas * temp[k] * (qv[k] + 0.622));
@@ -1830,6 +1923,50 @@ int P(th_oracle_mp_thompson_force)(const th_oracle *ctx,
     free(wd);
     free(Lws);
     return 0;
+}
+
+/* calc_effectRad, M:4834-4935: radiation effective radii of cloud water, cloud ice and snow (INOUT: levels without
+ * the species keep what the caller put there -- the scheme's driver presets 2.49E-6, 4.99E-6, 9.99E-6, M:1111-1113).
+ * is_aerosol_aware = .false.: nc(k) = Nt_c (M:4863). */
+void P(th_oracle_calc_effectRad)(const th_oracle *ctx, int nz,
+                                 const real *t1d, const real *p1d, const real *qv1d, const real *qc1d,
+                                 const real *nc1d, const real *qi1d, const real *ni1d, const real *qs1d,
+                                 real *re_qc1d, real *re_qi1d, real *re_qs1d)
+{
+    const th_view *o = (const th_view *)ctx->P(view);
+    static const real g_ratio[16] = { 0, 24, 60, 120, 210, 336, 504, 720, 990, 1320, 1716, 2184, 2730, 3360, 4080, 4896 };
+    const real *cse = o->cse;
+    for (int k = 0; k < nz; k++) {
+        real rho = 0.622 * p1d[k] / (R_gas * t1d[k] * (qv1d[k] + 0.622));
+        real rc = MAXD(R1, qc1d[k] * rho);
+        real nc = MAXD(R2, nc1d[k] * rho);
+        if (!o->is_aerosol_aware) nc = o->Nt_c;                         /* M:4863 */
+        real ri = MAXD(R1, qi1d[k] * rho);
+        real ni = MAXD(R2, ni1d[k] * rho);
+        real rs = MAXD(R1, qs1d[k] * rho);
+        if (!(rc <= R1 || nc <= R2)) {                                   /* M:4873-4884 */
+            int inu_c;
+            if (nc < 100) inu_c = 15;
+            else if (nc > 1.E10) inu_c = 2;
+            else { inu_c = NINT(1000.E6 / nc) + 2; if (inu_c > 15) inu_c = 15; }
+            double lamc = pow(nc * am_r * g_ratio[inu_c] / rc, o->obmr);
+            re_qc1d[k] = MAXD(2.51E-6, MIND((real)((double)0.5 * (double)(3. + inu_c) / lamc), 50.E-6));
+        }
+        if (!(ri <= R1 || ni <= R2)) {                                   /* M:4887-4893 */
+            double lami = pow(am_i * o->cig[2] * o->oig1 * ni / ri, o->obmi);
+            re_qi1d[k] = MAXD(5.01E-6, MIND((real)((double)0.5 * (double)(3. + mu_i) / lami), 125.E-6));
+        }
+        if (!(rs <= R1)) {                                               /* M:4896-4930; bm_s = 2: smo2 = smob */
+            real tc0 = MIND(-0.1, t1d[k] - 273.15);
+            real smob = rs * o->oams;
+            real smo2 = smob;
+            real loga_ = mom_loga(o->sa, tc0, cse[1]);
+            real a_ = pow((real)10.0, loga_);
+            real b_ = mom_b(o->sb, tc0, cse[1]);
+            real smoc = a_ * pow(smo2, b_);
+            re_qs1d[k] = MAXD(10.E-6, MIND(0.5 * (smoc / smob), 999.E-6));
+        }
+    }
 }
 
 /* non-aerosol defaults, M:958-964 (decision U2) */

@@ -187,6 +187,28 @@ static void table_Efsw(th_oracle *o)
 }
 
 /* ------------------------------------------------------------------ */
+/* table_dropEvap M:4400-4439: mass / number of droplets smaller than bin i for cloud water r_c(j) and number t_Nc(k).
+ * Only read under is_aerosol_aware (M:2850). */
+static void table_dropEvap(th_oracle *o)
+{
+    double N_c[nbc + 1], massc[nbc + 1];
+    for (int n = 1; n <= nbc; n++) massc[n] = am_r * pow(o->Dc[n], bm_r);
+    for (int k = 1; k <= nbc; k++) {
+        int nu_c = NINT(1000.E6 / o->t_Nc[k]) + 2; if (nu_c > 15) nu_c = 15;
+        for (int j = 1; j <= ntb_c; j++) {
+            double lamc = pow(o->t_Nc[k] * am_r * o->ccg[2][nu_c] * o->ocg1[nu_c] / o->r_c[j], o->obmr);
+            double N0_c = o->t_Nc[k] * o->ocg1[nu_c] * pow(lamc, o->cce[1][nu_c]);
+            for (int i = 1; i <= nbc; i++) {
+                N_c[i] = N0_c * th_powi(o->Dc[i], nu_c) * exp(-lamc * o->Dc[i]) * o->dtc[i];
+                double summ = 0., summ2 = 0.;
+                for (int n = 1; n <= i; n++) { summ = summ + massc[n] * N_c[n]; summ2 = summ2 + N_c[n]; }
+                o->tpc_wev[IX3(i, j, k, nbc, ntb_c)] = summ;
+                o->tnc_wev[IX3(i, j, k, nbc, ntb_c)] = summ2;
+            }
+        }
+    }
+}
+
 /* qr_acr_qg M:3698-3833 : one (k,m) slab */
 typedef struct { th_oracle *o; int km_s, km_e; const double *vr, *vg, *vs; } slab_job;
 
@@ -708,6 +730,9 @@ th_oracle *th_oracle_create(int iiwarm, double set_Nc, int l_sediment,
 
     table_Efrw(o);                                            /* M:766 */
     table_Efsw(o);                                            /* M:767 */
+    o->tnc_wev = talloc((size_t)nbc * ntb_c * nbc);
+    o->tpc_wev = talloc((size_t)nbc * ntb_c * nbc);
+    table_dropEvap(o);                                        /* M:771 */
     if (!iiwarm) {                                            /* M:773-791 */
         if (!(cache_path && cache_load(o, cache_path))) {
             qr_acr_qg(o);
@@ -728,8 +753,16 @@ void th_oracle_destroy(th_oracle *o)
     if (!o) return;
     tabent t[40]; int nt = table_list(o, t);
     for (int i = 0; i < nt; i++) free(*t[i].p);
-    free(o->view); free(o->view_p32n);
+    free(o->view); free(o->view_p32n); free(o->tnc_wev); free(o->tpc_wev);
     free(o);
+}
+
+void th_oracle_set_aerosol_aware(th_oracle *o, int flag)
+{
+    o->is_aerosol_aware = flag != 0;
+    free(o->view); free(o->view_p32n);
+    o->view = th_oracle_make_view(o);
+    o->view_p32n = th_oracle_make_view_p32n(o);
 }
 
 /* ------------------------------------------------------------------ */

@@ -124,6 +124,8 @@ struct th_oracle {
     double *tpi_qrfz, *tpg_qrfz, *tni_qrfz, *tnr_qrfz;
     double *tps_iaus, *tni_iaus, *tpi_ide;
     double *t_Efrw, *t_Efsw;
+    double *tnc_wev, *tpc_wev;        /* table_dropEvap M:4400-4439, (nbc, ntb_c, nbc): only read when is_aerosol_aware */
+    int is_aerosol_aware;             /* M:28 (.false. in KiD); th_oracle_set_aerosol_aware */
     int nthreads;
     /* what mp_thompson reads, in the arithmetic of each build of thompson_oracle_column.c (th_view there) */
     void *view, *view_p32n;

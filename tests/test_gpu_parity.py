@@ -202,3 +202,16 @@ def test_table_cache_roundtrip_through_reference_format(gpu_mixed, tmp_path):
         assert np.array_equal(pa, pb)
     finally:
         other.close()
+
+
+def test_effective_radii_match_oracle(gpu_mixed, oracle_mixed):
+    """calc_effectRad (M:4834-4935) on the device vs the oracle: cloud water, cloud ice, snow; absent species keep the preset."""
+    import torch
+    st = {k: np.concatenate([cases.config3(48)[k], cases.config5(48)[k], cases.edge_cases()[k]]) for k in cases.KEYS}
+    ref = oracle_mixed.calc_effectRad(st)
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in st.items()}
+    got = gpu_mixed.effective_radii(dev)
+    for g, r, name, preset in zip(got, ref, ("re_qc", "re_qi", "re_qs"), (2.49e-6, 4.99e-6, 9.99e-6)):
+        g = g.cpu().numpy()
+        assert np.max(np.abs(g - r) / r) < 1e-12, name
+        assert (g == preset).any() and (g != preset).any(), name
