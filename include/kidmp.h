@@ -48,13 +48,15 @@ typedef struct kidmp_ctx kidmp_ctx;
 /* Run-time switches the reference reads from KiD modules:
  *   iiwarm, set_Nc      `namelists` (M:22)
  *   l_sediment          `switches`  (M:20)  gates ice/snow/graupel fall only
- *   device              HIP device ordinal (one process per GPU)            */
+ *   device              HIP device ordinal (one process per GPU)
+ *   is_aerosol_aware    `module_mp_thompson09n`'s public LOGICAL (M:28)          */
 typedef struct kidmp_cfg {
     int32_t iiwarm;
     int32_t l_sediment;
     double  set_Nc;        /* cloud droplet number, cm^-3 (Nt_c = set_Nc*1e6, M:381) */
     int32_t device;
-    int32_t reserved;
+    int32_t is_aerosol_aware;   /* the module's public switch (M:28; .false. in KiD): prognostic droplet number, aerosol
+                                   activation / DeMott / Koop nucleation, scavenging, droplet evaporation */
 } kidmp_cfg;
 
 /* thompson_init (M:374-797): computes the gamma/rate constants on the host and

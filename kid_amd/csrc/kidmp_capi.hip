@@ -204,7 +204,7 @@ __global__ void k_sanity_final(const unsigned long long *acc, double *out15)
 // calc_effectRad, M:4834-4935: effective radii of cloud water, cloud ice and snow for radiation coupling.  Pointwise in
 // (column, level); re_* are INOUT (a level without the species keeps the caller's value, M:4873/4888/4897).  The
 // reference's column-wide has_qc/has_qi/has_qs flags only skip loops whose bodies test the level again.
-struct RadConsts { double Nt_c, cig2, oig1, oams, cse1, sa[10], sb[10]; };
+struct RadConsts { double Nt_c, cig2, oig1, oams, cse1, sa[10], sb[10]; int aero; };
 __global__ void k_effective_radii(int64_t n, RadConsts c, const double *__restrict__ t, const double *__restrict__ p,
                                   const double *__restrict__ qv, const double *__restrict__ qc, const double *__restrict__ nc1,
                                   const double *__restrict__ qi, const double *__restrict__ ni1, const double *__restrict__ qs,
@@ -216,7 +216,7 @@ __global__ void k_effective_radii(int64_t n, RadConsts c, const double *__restri
     const double rho = 0.622 * p[i] / (Rgas * t[i] * (qv[i] + 0.622));
     const double rc = fmax(R1, qc[i] * rho);
     double nc = fmax(R2, nc1[i] * rho);
-    nc = c.Nt_c;                                                        // .NOT. is_aerosol_aware, M:4863
+    if (!c.aero) nc = c.Nt_c;                                           // .NOT. is_aerosol_aware, M:4863
     const double ri = fmax(R1, qi[i] * rho), ni = fmax(R2, ni1[i] * rho), rs = fmax(R1, qs[i] * rho);
     if (!(rc <= R1 || nc <= R2)) {                                      // M:4873-4884
         int inu_c;
@@ -259,7 +259,7 @@ std::vector<Named> table_dir(const Tables &t)
         {"tpi_qrfz", t.tpi_qrfz, N_QRFZ}, {"tpg_qrfz", t.tpg_qrfz, N_QRFZ}, {"tni_qrfz", t.tni_qrfz, N_QRFZ},
         {"tnr_qrfz", t.tnr_qrfz, N_QRFZ},
         {"tps_iaus", t.tps_iaus, N_IAUS}, {"tni_iaus", t.tni_iaus, N_IAUS}, {"tpi_ide", t.tpi_ide, N_IAUS},
-        {"t_Efrw", t.t_Efrw, N_EF}, {"t_Efsw", t.t_Efsw, N_EF},
+        {"t_Efrw", t.t_Efrw, N_EF}, {"t_Efsw", t.t_Efsw, N_EF}, {"tnc_wev", t.tnc_wev, N_WEV},
         {"racs_rec", t.racs_rec, N_RACS * RACS_REC}, {"racg_rec", t.racg_rec, N_RACG * RACG_REC},
         {"qrfz_rec", t.qrfz_rec, N_QRFZ * QRFZ_REC},
     };
@@ -431,9 +431,10 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
                             const double *p, const double *w, const double *dz,
                             double *ppt, double *rates, int32_t *nstep, void *stream)
 {
-    (void)w;   // w1d only feeds activ_ncloud (is_aerosol_aware, M:2797)
+    // w1d only feeds activ_ncloud (is_aerosol_aware, M:2797): optional otherwise
     const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
     if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
+    if (ctx->cfg.is_aerosol_aware && !w) return fail(ctx, KIDMP_EINVAL, "kidmp: an aerosol-aware context needs the updraft profile w");
     GUARD(ctx);
     if (int rc = check_on_device(ctx, qv, "qv")) return rc;
     if (int rc = check_on_device(ctx, ppt, "ppt")) return rc;
@@ -442,6 +443,7 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     a.nc = nc; a.nwfa = nwfa; a.nifa = nifa; a.t = t; a.p = p; a.dz = dz;
     a.ppt = ppt; a.rates = rates; a.nstep = nstep;
     a.cslot = ctx->cslot; a.tables = ctx->tables; a.iiwarm = ctx->cfg.iiwarm != 0;
+    a.aero = ctx->cfg.is_aerosol_aware != 0; a.w = w;
     a.ncol = ncol; a.nz = nz; a.dt = dt;
     a.debug_stop = ctx->debug_stop;
     if (ncol == 0) return KIDMP_OK;
@@ -481,7 +483,7 @@ int kidmp_batch_step_host_diag(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double 
     if (ncol == 0) return KIDMP_OK;
     GUARD(ctx);
     const size_t prof = size_t(ncol) * size_t(nz);
-    const size_t need = (14 * prof + 4 * size_t(ncol) + (rates ? size_t(KIDMP_NRATES) * prof : 0)
+    const size_t need = (15 * prof + 4 * size_t(ncol) + (rates ? size_t(KIDMP_NRATES) * prof : 0)
                          + (nstep ? (4 * size_t(ncol) + 1) / 2 : 0)) * sizeof(double);
     if (need > ctx->stage_bytes) {
         if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -494,6 +496,7 @@ int kidmp_batch_step_host_diag(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double 
     double *dio[12], *din[2];
     for (int i = 0; i < 12; ++i) { dio[i] = d; d += prof; }
     for (int i = 0; i < 2; ++i) { din[i] = d; d += prof; }
+    double *dw = d; d += prof;                               // the updraft: only aerosol-aware contexts read it
     double *dppt = d; d += 4 * size_t(ncol);
     double *drates = rates ? d : nullptr;
     if (rates) d += size_t(KIDMP_NRATES) * prof;
@@ -501,9 +504,10 @@ int kidmp_batch_step_host_diag(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double 
     hipStream_t s = ctx->stream;
     for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(dio[i], io[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
     for (int i = 0; i < 2; ++i) HIPTRY(ctx, hipMemcpyAsync(din[i], in[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
+    if (ctx->cfg.is_aerosol_aware && w) HIPTRY(ctx, hipMemcpyAsync(dw, w, prof * sizeof(double), hipMemcpyHostToDevice, s));
     HIPTRY(ctx, hipMemcpyAsync(dppt, ppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyHostToDevice, s));
     int rc = kidmp_batch_step_device(ctx, ncol, nz, dt, dio[0], dio[1], dio[2], dio[3], dio[4], dio[5], dio[6], dio[7],
-                                     dio[8], dio[9], dio[10], dio[11], din[0], w, din[1], dppt, drates, dnstep, s);
+                                     dio[8], dio[9], dio[10], dio[11], din[0], w ? dw : nullptr, din[1], dppt, drates, dnstep, s);
     if (rc) return rc;
     for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(io[i], dio[i], prof * sizeof(double), hipMemcpyDeviceToHost, s));
     HIPTRY(ctx, hipMemcpyAsync(ppt, dppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyDeviceToHost, s));
@@ -529,9 +533,9 @@ int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt
                               const float *p, const float *w, const float *dz,
                               float *ppt, double *rates, int32_t *nstep, int32_t arith, void *stream)
 {
-    (void)w;
     const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
     if (int rc = check_step_args(ctx, ncol, nz, double(dt), ptrs, 15)) return rc;
+    if (ctx->cfg.is_aerosol_aware && !w) return fail(ctx, KIDMP_EINVAL, "kidmp: an aerosol-aware context needs the updraft profile w");
     if (arith != KIDMP_ARITH_P32N && arith != KIDMP_ARITH_F32) return fail(ctx, KIDMP_EINVAL, "kidmp32: arith must be KIDMP_ARITH_P32N or KIDMP_ARITH_F32");
     GUARD(ctx);
     if (int rc = check_on_device(ctx, qv, "qv")) return rc;
@@ -541,6 +545,7 @@ int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt
     a.nc = nc; a.nwfa = nwfa; a.nifa = nifa; a.t = t; a.p = p; a.dz = dz;
     a.ppt = ppt; a.rates = rates; a.nstep = nstep;
     a.cslot = ctx->cslot; a.tables = ctx->tables; a.iiwarm = ctx->cfg.iiwarm != 0;
+    a.aero = ctx->cfg.is_aerosol_aware != 0; a.w = w;
     a.ncol = ncol; a.nz = nz; a.dt = dt;
     a.debug_stop = ctx->debug_stop;
     if (ncol == 0) return KIDMP_OK;
@@ -564,7 +569,7 @@ int kidmp32_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt,
     if (ncol == 0) return KIDMP_OK;
     GUARD(ctx);
     const size_t prof = size_t(ncol) * size_t(nz);
-    const size_t need = (14 * prof + 4 * size_t(ncol)) * sizeof(float) + (rates ? size_t(KIDMP_NRATES) * prof : 0) * sizeof(double)
+    const size_t need = (15 * prof + 4 * size_t(ncol)) * sizeof(float) + (rates ? size_t(KIDMP_NRATES) * prof : 0) * sizeof(double)
                         + (nstep ? 4 * size_t(ncol) * sizeof(int32_t) : 0) + 64;
     if (need > ctx->stage_bytes) {
         if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -579,14 +584,16 @@ int kidmp32_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt,
     float *dio[12], *din[2];
     for (int i = 0; i < 12; ++i) { dio[i] = d; d += prof; }
     for (int i = 0; i < 2; ++i) { din[i] = d; d += prof; }
+    float *dw = d; d += prof;
     float *dppt = d; d += 4 * size_t(ncol);
     int32_t *dnstep = nstep ? reinterpret_cast<int32_t *>(d) : nullptr;
     hipStream_t s = ctx->stream;
     for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(dio[i], io[i], prof * sizeof(float), hipMemcpyHostToDevice, s));
     for (int i = 0; i < 2; ++i) HIPTRY(ctx, hipMemcpyAsync(din[i], in[i], prof * sizeof(float), hipMemcpyHostToDevice, s));
+    if (ctx->cfg.is_aerosol_aware && w) HIPTRY(ctx, hipMemcpyAsync(dw, w, prof * sizeof(float), hipMemcpyHostToDevice, s));
     HIPTRY(ctx, hipMemcpyAsync(dppt, ppt, 4 * size_t(ncol) * sizeof(float), hipMemcpyHostToDevice, s));
     int rc = kidmp32_batch_step_device(ctx, ncol, nz, dt, dio[0], dio[1], dio[2], dio[3], dio[4], dio[5], dio[6], dio[7],
-                                       dio[8], dio[9], dio[10], dio[11], din[0], w, din[1], dppt, drates, dnstep, arith, s);
+                                       dio[8], dio[9], dio[10], dio[11], din[0], w ? dw : nullptr, din[1], dppt, drates, dnstep, arith, s);
     if (rc) return rc;
     for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(io[i], dio[i], prof * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPTRY(ctx, hipMemcpyAsync(ppt, dppt, 4 * size_t(ncol) * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -710,6 +717,7 @@ int kidmp_effective_radii_device(kidmp_ctx *ctx, int64_t n, const double *t, con
     if (int rc = check_on_device(ctx, t, "t")) return rc;
     if (int rc = check_on_device(ctx, re_qc, "re_qc")) return rc;
     RadConsts c{};
+    c.aero = ctx->cfg.is_aerosol_aware != 0;
     c.Nt_c = ctx->hc.Nt_c; c.cig2 = ctx->hc.cig[1]; c.oig1 = ctx->hc.oig1; c.oams = ctx->hc.oams; c.cse1 = ctx->hc.cse[0];
     for (int i = 0; i < 10; ++i) { c.sa[i] = ctx->hc.sa[i]; c.sb[i] = ctx->hc.sb[i]; }
     const int T = 256;

@@ -24,6 +24,8 @@ struct StepArgsT {
     R *scratch;           // [ncol][nz] work profile owned by the context (block-K rain mvd, pass 1 -> pass 3)
     int32_t cslot;        // slot of this context's Consts in constant memory (upload_consts)
     int32_t iiwarm;       // the context's iiwarm switch: selects the warm-rain instantiation of the kernel
+    int32_t aero;         // the context's is_aerosol_aware switch (M:28): selects the aerosol-aware instantiation
+    const R *w;           // IN: updraft, read only by activ_ncloud (aerosol-aware contexts, M:2797); may be null otherwise
     Tables tables;
     int64_t ncol;
     int32_t nz;

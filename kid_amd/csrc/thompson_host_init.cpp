@@ -200,6 +200,9 @@ void host_init(int iiwarm, int l_sediment, double set_Nc, Consts &c, Bins &b)
     c.r_s1 = b.r_s[0];
     c.r_g1 = b.r_g[0];
     c.Nt_i1 = b.Nt_i[0];
+    c.t_Nc1 = b.t_Nc[0];
+    c.nic1 = int32_t(std::log(b.t_Nc[nbins - 1] / b.t_Nc[0]));      // INTEGER nic1 truncates DLOG(...) = 7.93, M:195, M:670
+    c.pad_ = 0;
 }
 
 }  // namespace kidmp

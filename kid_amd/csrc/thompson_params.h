@@ -46,6 +46,7 @@ constexpr int64_t N_QRFZ = int64_t(ntb_r) * ntb_r1 * ntb_tc;
 constexpr int64_t N_QCFZ = int64_t(ntb_c) * ntb_tc;
 constexpr int64_t N_IAUS = int64_t(ntb_i) * ntb_i1;
 constexpr int64_t N_EF = int64_t(nbins) * nbins;
+constexpr int64_t N_WEV = int64_t(nbins) * ntb_c * nbins;
 
 // ---- values thompson_init computes once (M:442-602); 0-based C arrays hold
 // the Fortran element n at index n-1 ----
@@ -72,6 +73,9 @@ struct Consts {
     double Dr1, Drn, Ds1, Dsn;
     // axis minima used as thresholds in the solver
     double r_c1, r_i1, r_r1, r_s1, r_g1, Nt_i1;
+    // droplet-number axis of tnc_wev (aerosol-aware droplet evaporation, M:2828): t_Nc(1) and the INTEGER nic1 of M:670
+    double t_Nc1;
+    int32_t nic1, pad_;
 };
 
 // bins and axes needed only while building tables (device copies)
@@ -95,6 +99,7 @@ struct Tables {
     double *tpi_qrfz, *tpg_qrfz, *tni_qrfz, *tnr_qrfz;
     double *tps_iaus, *tni_iaus, *tpi_ide;
     double *t_Efrw, *t_Efsw;
+    double *tnc_wev;    // table_dropEvap M:4400-4439, (nbc, ntb_c, nbc): read only by aerosol-aware contexts (M:2850)
     // interleaved records read by the column kernel
     double *racs_rec;   // [N_RACS][10]: tmr_racs1,tcr_sacr1,tmr_racs2,tcr_sacr2,tcs_racs1,tms_sacr1,tnr_racs1,tnr_racs2,tnr_sacr1,tnr_sacr2
     double *racg_rec;   // [N_RACG][5] : tmr_racg,tcr_gacr,tnr_racg,tnr_gacr,tcg_racg

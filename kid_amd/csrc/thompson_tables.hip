@@ -423,6 +423,33 @@ __global__ void k_iaus(const Bins *__restrict__ b, const Consts *__restrict__ cp
 }
 
 // rebuild the interleaved per-cell records from the planar tables (after kidmp_load_table_cache)
+// table_dropEvap M:4400-4439: tnc_wev(i,j,k) = number of droplets in the bins up to Dc(i) of a gamma distribution with
+// cloud water r_c(j) and number t_Nc(k).  One thread per (j,k); the reference re-sums bins 1..i for every i in the same
+// order, which is the running sum kept here.  (tpc_wev, the mass counterpart, is only used in a commented-out line.)
+__global__ void k_dropevap(const Bins *__restrict__ b, const Consts *__restrict__ cp, double *__restrict__ tnc_wev)
+{
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= ntb_c * nbins) return;
+    const int j = id % ntb_c, k = id / ntb_c;
+    const Consts &c = *cp;
+    int nu_c = int(lround(1000.E6 / b->t_Nc[k])) + 2;
+    nu_c = nu_c < 15 ? nu_c : 15;
+    const double lamc = pow(b->t_Nc[k] * am_r * c.ccg[1][nu_c - 1] * c.ocg1[nu_c - 1] / b->r_c[j], c.obmr);
+    const double N0_c = b->t_Nc[k] * c.ocg1[nu_c - 1] * pow(lamc, c.cce[0][nu_c - 1]);
+    double summ2 = 0.;
+    for (int i = 0; i < nbins; ++i) {
+        double dn = 1.;                                      // Dc(i)**nu_c: real**integer by squaring (__powidf2)
+        {
+            double a = b->Dc[i];
+            int e = nu_c;
+            for (;;) { if (e & 1) dn *= a; e /= 2; if (e == 0) break; a *= a; }
+        }
+        const double N_c = N0_c * dn * exp(-lamc * b->Dc[i]) * b->dtc[i];
+        summ2 = summ2 + N_c;
+        tnc_wev[i + int64_t(nbins) * (j + int64_t(ntb_c) * k)] = summ2;
+    }
+}
+
 __global__ void k_repack(Tables t)
 {
     const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -462,6 +489,7 @@ hipError_t alloc_tables(Tables &t)
     for (auto p : p2c) HIPCHK(grab(p, N_QCFZ));
     for (auto p : p2i) HIPCHK(grab(p, N_IAUS));
     for (auto p : pe) HIPCHK(grab(p, N_EF));
+    HIPCHK(grab(&t.tnc_wev, N_WEV));
     HIPCHK(grab(&t.racs_rec, N_RACS * RACS_REC));
     HIPCHK(grab(&t.racg_rec, N_RACG * RACG_REC));
     HIPCHK(grab(&t.qrfz_rec, N_QRFZ * QRFZ_REC));
@@ -490,6 +518,7 @@ hipError_t build_tables(const Consts *d_consts, const Bins *d_bins, int iiwarm, 
     const int T = 256;
     hipLaunchKernelGGL(k_efrw, dim3((nbins * nbins + T - 1) / T), dim3(T), 0, s, d_bins, t.t_Efrw);   // M:766
     hipLaunchKernelGGL(k_efsw, dim3((nbins * nbins + T - 1) / T), dim3(T), 0, s, d_bins, d_consts, t.t_Efsw);   // M:767
+    hipLaunchKernelGGL(k_dropevap, dim3((ntb_c * nbins + T - 1) / T), dim3(T), 0, s, d_bins, d_consts, t.tnc_wev);   // M:771
     if (!iiwarm) {                                                                                   // M:773-791
         hipLaunchKernelGGL(k_racg, dim3(ntb_g, ntb_r * ntb_r1), dim3(TBW * WAVE), 0, s, d_bins, d_consts, t);
         hipLaunchKernelGGL(k_racs, dim3(ntb_t, ntb_r * ntb_r1), dim3(TBW * WAVE), 0, s, d_bins, d_consts, t);

@@ -41,7 +41,7 @@ module module_mp_thompson09n
   private
 
   public :: thompson_init, mp_thompson, mp_thompson_batch, thompson_finalize
-  logical, public :: is_aerosol_aware = .false.          ! M:28 (only .false. is supported)
+  logical, public :: is_aerosol_aware = .false.          ! M:28 (read at thompson_init)
   logical, public :: l_rate_diagnostics = .true.         ! replay the save_dg calls of M:2962-3124
   integer, public :: kidmp_device = 0                    ! HIP device ordinal of this process (one process per GPU)
   character(4), public :: kidmp_arith = 'p64 '           ! 'p64', or with 4-byte default REAL 'p32n' / 'f32'
@@ -59,7 +59,7 @@ module module_mp_thompson09n
      integer(c_int32_t) :: l_sediment
      real(c_double)     :: set_Nc
      integer(c_int32_t) :: device
-     integer(c_int32_t) :: reserved
+     integer(c_int32_t) :: is_aerosol_aware
   end type kidmp_cfg
 
   type(c_ptr), save :: ctx = c_null_ptr
@@ -134,17 +134,13 @@ contains
     character(16) :: envdev
     integer :: envstat
     if (c_associated(ctx)) return                         ! micro_init guard, M:384-389
-    if (is_aerosol_aware) then
-       write(*,*) 'module_mp_thompson09n: is_aerosol_aware=.true. is not supported by the MI355X build'
-       stop 1
-    end if
     cfg%iiwarm = merge(1_c_int32_t, 0_c_int32_t, iiwarm)
     cfg%l_sediment = merge(1_c_int32_t, 0_c_int32_t, l_sediment)
     cfg%set_Nc = real(set_Nc, c_double)
     call get_environment_variable('KIDMP_DEVICE', envdev, status=envstat)
     if (envstat == 0 .and. len_trim(envdev) > 0) read(envdev, *, iostat=envstat) kidmp_device
     cfg%device = int(kidmp_device, c_int32_t)
-    cfg%reserved = 0
+    cfg%is_aerosol_aware = merge(1_c_int32_t, 0_c_int32_t, is_aerosol_aware)
     rc = kidmp_init(cfg, ctx)
     call stop_on_error(rc, 'thompson_init')
   end subroutine thompson_init

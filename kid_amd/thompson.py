@@ -37,7 +37,7 @@ class KidmpError(RuntimeError):
 
 class _Cfg(C.Structure):
     _fields_ = [("iiwarm", C.c_int32), ("l_sediment", C.c_int32), ("set_Nc", C.c_double),
-                ("device", C.c_int32), ("reserved", C.c_int32)]
+                ("device", C.c_int32), ("is_aerosol_aware", C.c_int32)]
 
 
 def lib_path():
@@ -126,10 +126,11 @@ class ThompsonMP:
     """One context = the module state of module_mp_thompson09n after thompson_init:
     constants on the host, lookup tables resident in HBM."""
 
-    def __init__(self, iiwarm=False, set_Nc=100.0, l_sediment=True, device=0):
+    def __init__(self, iiwarm=False, set_Nc=100.0, l_sediment=True, device=0, aerosol_aware=False):
         self._h = None
         L = load_library()
-        cfg = _Cfg(int(bool(iiwarm)), int(bool(l_sediment)), float(set_Nc), int(device), 0)
+        cfg = _Cfg(int(bool(iiwarm)), int(bool(l_sediment)), float(set_Nc), int(device), int(bool(aerosol_aware)))
+        self.aerosol_aware = bool(aerosol_aware)
         h = _vp()
         rc = L.kidmp_init(C.byref(cfg), C.byref(h))
         if rc != 0:

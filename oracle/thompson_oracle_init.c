@@ -769,6 +769,7 @@ void th_oracle_set_aerosol_aware(th_oracle *o, int flag)
 const double *th_oracle_table(const th_oracle *oc, const char *name, int *ndim, int dims[4])
 {
     th_oracle *o = (th_oracle *)oc;
+    if (!strcmp(name, "tnc_wev")) { *ndim = 3; dims[0] = nbc; dims[1] = ntb_c; dims[2] = nbc; return o->tnc_wev; }
     tabent t[40]; int nt = table_list(o, t);
     for (int i = 0; i < nt; i++)
         if (!strcmp(name, t[i].name)) {

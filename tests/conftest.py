@@ -50,3 +50,22 @@ def gpu_warm():
     m = ThompsonMP(iiwarm=True)
     yield m
     m.close()
+
+
+@pytest.fixture(scope="session")
+def oracle_mixed_aero():
+    from oracle.oracle import Oracle
+    o = Oracle(iiwarm=False, aerosol_aware=True)
+    yield o
+    o.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_mixed_aero():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible; the HIP path has no CPU fallback")
+    from kid_amd import ThompsonMP
+    m = ThompsonMP(iiwarm=False, aerosol_aware=True)
+    yield m
+    m.close()
