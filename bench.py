@@ -59,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-workloads", action="store_true", help="time the named workload only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank); gloo only to rehearse N ranks on fewer GPUs")
+    ap.add_argument("--arith", default="p64", choices=["p64", "p32n", "f32"],
+                    help="p64 = the parity build (default, the metric's dtype); p32n = the reference as shipped (binary32 state, "
+                         "binary64 rates); f32 = all binary32 (BASELINE config 5's precision sweep)")
     ap.add_argument("--lib", default=None, help="an explicitly named build of libkidmp.so (A/B and profiling builds)")
     ap.add_argument("--rehearse-launcher", action="store_true",
                     help="CPU-only boxes: exercise launcher + rendezvous + reduction with NO physics (value is 0)")
@@ -269,7 +272,7 @@ def run_rank(args):
             shard = _RehearsalShard(ncol, rank)
         else:
             st, iiwarm, desc = make_workload(name, ncol, rank)
-            shard = ShardedColumns(st, rank, world, local, iiwarm, local=True)
+            shard = ShardedColumns(st, rank, world, local, iiwarm, local=True, arith=args.arith)
         ev0 = ev1 = None
         if not rehearse:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -292,7 +295,8 @@ def run_rank(args):
         sync_all()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         kern_ms = ev0.elapsed_time(ev1) / steps if ev0 else 0.0   # average launch duration (launch-to-launch)
-        res = {"workload": desc + ", nz=120, dt=10 s, fp64", "name": name, "ncol_per_gpu": ncol, "iiwarm": iiwarm,
+        res = {"workload": desc + ", nz=120, dt=10 s, " + {"p64": "fp64", "p32n": "P32n (binary32 state, binary64 rates)",
+                                                            "f32": "fp32"}[args.arith], "name": name, "ncol_per_gpu": ncol, "iiwarm": iiwarm,
                "value": 0.0 if rehearse else ncol * world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
                "kernel_ms": kern_ms, "precip_domain_sums": [float(x) for x in diag["precip"].cpu().tolist()],
                "sanity_max_qc_qr_nr_qs_qi_qg_ni": [float(x) for x in diag["sanity"][:7].cpu().tolist()],
@@ -301,14 +305,17 @@ def run_rank(args):
 
     def roofline(shard, res):
         ncol, kern_s = res["ncol_per_gpu"], res["kernel_ms"] * 1e-3
-        achieved = ALGO_BYTES_FP64 * ncol / kern_s
+        algo_bytes = ALGO_BYTES_FP64 if args.arith == "p64" else ALGO_BYTES_FP64 // 2      # fp32 9 616 B
+        achieved = algo_bytes * ncol / kern_s
         fp = shard.model.kernel_fingerprint()
         prof = load_pmc_profile(res["name"], ncol, fp)
         out = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "frac": achieved / HBM_PEAK, "traffic": None, "traffic_bytes_per_launch": None, "valu_frac": None,
                "kernel": shard.model.kernel_name(), "kernel_ms": res["kernel_ms"], "kernel_fingerprint": fp,
-               "algorithmic_bytes_per_column_step": ALGO_BYTES_FP64}
-        if res["iiwarm"]:
+               "algorithmic_bytes_per_column_step": algo_bytes}
+        if args.arith != "p64":
+            prof = None                                       # the committed PMC profiles are of the p64 code object
+        if res["iiwarm"] and args.arith == "p64":
             out["frac_warm_only_bytes"] = ALGO_BYTES_WARM * ncol / kern_s / HBM_PEAK
             out["algorithmic_bytes_warm_only"] = ALGO_BYTES_WARM
         if prof is not None and "FETCH_SIZE" in prof and "WRITE_SIZE" in prof:
@@ -336,7 +343,7 @@ def run_rank(args):
             "metric": "thompson_mp_column_steps_per_sec", "value": res["value"], "unit": "column-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64",
+            "vs_baseline": None, "dtype": {"p64": "f64", "p32n": "f32 state / f64 rates", "f32": "f32"}[args.arith],
             "data": "none (launcher rehearsal without a GPU; no physics ran)" if rehearse else "synthetic",
             "config": {"workload": res["workload"], "ncol_per_gpu": ncol, "nz": NZ, "dt": DT,
                        "parallelism": "columns sharded over ranks, no halo, no data-path collective; one RCCL "
@@ -348,6 +355,8 @@ def run_rank(args):
         if not rehearse:
             out["roofline"] = roofline(shard, res)
             out["init_seconds"] = shard.model.init_seconds
+    if args.arith != "p64":
+        args.no_cpu_baseline = args.no_other_workloads = True   # the accuracy leg and the companion workloads are the p64 build's
     if not rehearse and not args.no_cpu_baseline and world == 1:   # N = 1 only: the host cores are shared by the ranks
         out["cpu_baseline"] = cpu_baseline(shard.model, st, res["iiwarm"])
     if not rehearse:

@@ -38,7 +38,7 @@ class ShardedColumns:
     domain diagnostics over all ranks -- the one exchange of the path."""
 
     def __init__(self, state, rank, world, device, iiwarm, set_Nc=100.0, l_sediment=True, want_rates=False,
-                 local=False):
+                 local=False, arith="p64"):
         """state: dict of [ncol, nz] float64 arrays (numpy or torch) -- the GLOBAL batch, of which this rank takes its
         contiguous range; or, with local=True, this rank's own columns (weak-scaling runs generate them per rank)."""
         import torch
@@ -52,15 +52,21 @@ class ShardedColumns:
             self.ncol_global = n
         self.model = ThompsonMP(iiwarm=iiwarm, set_Nc=set_Nc, l_sediment=l_sediment, device=self.device)
         dev = torch.device("cuda", self.device)
-        self.st = {k: torch.as_tensor(v[self.lo:self.hi]).contiguous().to(dev) for k, v in state.items()}
+        # arith: "p64" (binary64 state, the parity build) or the binary32-state builds "p32n" / "f32" (kidmp32_*)
+        self.arith = arith
+        dt_state = torch.float64 if arith == "p64" else torch.float32
+        self.st = {k: torch.as_tensor(v[self.lo:self.hi]).contiguous().to(dev).to(dt_state) for k, v in state.items()}
         self.ncol, self.nz = self.st["qv"].shape
-        self.ppt = torch.zeros(self.ncol, 4, dtype=torch.float64, device=dev)
+        self.ppt = torch.zeros(self.ncol, 4, dtype=dt_state, device=dev)
         self.rates = torch.zeros(self.ncol, NRATES, self.nz, dtype=torch.float64, device=dev) if want_rates else None
 
     def step(self, dt):
         """One mp_thompson advance of every column of the shard, asynchronous on torch's current stream of the
         shard's device."""
-        self.model.batch_step(self.st, dt, self.ppt, rates=self.rates)
+        if self.arith == "p64":
+            self.model.batch_step(self.st, dt, self.ppt, rates=self.rates)
+        else:
+            self.model.batch_step32(self.st, dt, self.ppt, arith=self.arith, rates=self.rates)
 
     def synchronize(self):
         import torch
@@ -72,8 +78,12 @@ class ShardedColumns:
         the maxima); cpu_collective=True moves them to the host first (gloo rehearsals)."""
         import torch
         import torch.distributed as dist
-        precip = self.model.reduce_ppt(self.ppt)
-        sanity = self.model.sanity(self.st)
+        if self.arith == "p64":
+            precip = self.model.reduce_ppt(self.ppt)
+            sanity = self.model.sanity(self.st)
+        else:                                                  # the diagnostics kernels are binary64: convert the shard's view
+            precip = self.model.reduce_ppt(self.ppt.double())
+            sanity = self.model.sanity({k: self.st[k].double() for k in self.model.SANITY_NEG})
         rates = self.model.reduce_rates(self.rates) if self.rates is not None else None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             # ONE collective: every rank contributes its [4 + 15 (+ 36 nz)] vector, the sums and maxima are then formed
