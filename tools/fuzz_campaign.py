@@ -24,13 +24,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=40)
     ap.add_argument("--ncol", type=int, default=1000)
+    ap.add_argument("--aerosol-aware", action="store_true", help="both sides with is_aerosol_aware (random updrafts and aerosol loads)")
     args = ap.parse_args()
-    o, m = Oracle(iiwarm=False), ThompsonMP(iiwarm=False)
+    o, m = Oracle(iiwarm=False, aerosol_aware=args.aerosol_aware), ThompsonMP(iiwarm=False, aerosol_aware=args.aerosol_aware)
     tot = dict(columns=0, levels=0, excluded=0, cols_bad=0, gt1e7=0, gt1e5=0, worst=0.0, precip_worst=0.0)
     for seed in range(100, 100 + args.seeds):
         nz = (120, 120, 77, 200, 64, 128)[seed % 6]
         dt = (10.0, 10.0, 2.0, 10.0, 5.0, 10.0)[seed % 6]
         st = fuzz_columns(args.ncol, nz, seed)
+        if args.aerosol_aware:
+            rng = np.random.default_rng(1000 + seed)
+            st["w"] = np.ascontiguousarray(10.0 ** rng.uniform(-2.5, 1.3, size=st["qv"].shape) * rng.choice([1.0, 1.0, -1.0], size=st["qv"].shape))
+            st["nwfa"] = np.ascontiguousarray(st["nwfa"] * 10.0 ** rng.uniform(-1.0, 2.0, size=st["qv"].shape))
+            st["nifa"] = np.ascontiguousarray(st["nifa"] * 10.0 ** rng.uniform(-1.0, 3.0, size=st["qv"].shape))
         got = {k: v.copy() for k, v in st.items()}
         gppt, _ = m.batch_step_host(got, dt)
         cmp = branch_aware_compare(o, st, dt, got, gppt, depletion=1e-5)
