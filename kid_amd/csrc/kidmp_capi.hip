@@ -334,7 +334,7 @@ int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const v
     if (ncol < 0) return fail(ctx, KIDMP_EINVAL, "kidmp: ncol < 0");
     if (nz < 2 || nz > KIDMP_MAX_NZ) return fail(ctx, KIDMP_EINVAL, "kidmp: nz outside [2, KIDMP_MAX_NZ]");
     if (!(dt > 0.)) return fail(ctx, KIDMP_EINVAL, "kidmp: dt must be > 0");
-    for (int i = 0; i < nptr; ++i)
+    for (int i = 0; i < nptr && ncol > 0; ++i)                 // an empty batch has nothing to point at
         if (!ptrs[i]) return fail(ctx, KIDMP_EINVAL, "kidmp: null array argument");
     return KIDMP_OK;
 }

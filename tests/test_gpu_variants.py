@@ -147,3 +147,31 @@ def test_hip_graph_capture_of_steps(gpu_mixed):
     for k in cases.KEYS:
         assert torch.equal(graphed[k], eager[k]), k
     assert torch.equal(ppt_g, ppt_e)
+
+
+def test_c_abi_argument_checks_binary32_and_diagnostics(gpu_mixed):
+    """The round-2 entries refuse bad arguments with a status code, like the rest of the C ABI."""
+    import torch
+    from kid_amd import KidmpError
+    from kid_amd.thompson import load_library
+    L = load_library()
+    st = {k: np.ascontiguousarray(v[:2].astype(np.float32)) for k, v in cases.edge_cases().items()}
+    fp = C.POINTER(C.c_float)
+    args = [st[k].ctypes.data_as(fp) for k in cases.KEYS]
+    ppt = np.zeros((2, 4), dtype=np.float32)
+    rc = L.kidmp32_batch_step_host(gpu_mixed._h, 2, 120, 10.0, *args, ppt.ctypes.data_as(fp), None, None, 7)      # unknown arith
+    assert rc == -1 and b"arith" in L.kidmp_last_error(gpu_mixed._h)
+    rc = L.kidmp32_batch_step_host(gpu_mixed._h, 2, 120, -1.0, *args, ppt.ctypes.data_as(fp), None, None, 0)      # dt <= 0
+    assert rc == -1
+    assert L.kidmp32_batch_step_host(None, 2, 120, 10.0, *args, ppt.ctypes.data_as(fp), None, None, 0) == -5      # no context
+    dev = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+    with pytest.raises(KidmpError):
+        gpu_mixed.batch_step32(dev, 10.0, torch.zeros(2, 4, dtype=torch.float64, device="cuda"))                   # ppt must be float32
+    with pytest.raises(KidmpError):
+        gpu_mixed.batch_step(dev, 10.0, torch.zeros(2, 4, dtype=torch.float64, device="cuda"))                     # float32 state into the fp64 entry
+    assert L.kidmp_reduce_rates_device(gpu_mixed._h, 4, 1, None, None, None) == -1
+    assert L.kidmp_sanity_device(gpu_mixed._h, 10, *([None] * 9), None) == -1
+    assert L.kidmp_effective_radii_device(gpu_mixed._h, 10, *([None] * 11), None) == -1
+    # an empty batch is fine everywhere
+    e32 = {k: torch.zeros(0, 120, dtype=torch.float32, device="cuda") for k in cases.KEYS}
+    gpu_mixed.batch_step32(e32, 10.0, torch.zeros(0, 4, dtype=torch.float32, device="cuda"))
