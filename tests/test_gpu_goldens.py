@@ -43,3 +43,17 @@ def test_edge_cases_and_kats_against_committed_vectors(gpu_mixed):
 
 def test_kat_a_warm_against_committed_vectors(gpu_warm):
     _check(gpu_warm, "kata_warm")
+
+
+def test_aerosol_aware_against_committed_vectors(gpu_mixed_aero):
+    A = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_goldens_aero.npz"))
+    st = {k: np.ascontiguousarray(A["in_" + k].copy()) for k in KEYS}
+    ppt, _ = gpu_mixed_aero.batch_step_host(st, 10.0)
+    flagged = A["flags"] != 0
+    for k in OUT:
+        ref = A["out_" + k]
+        e = np.abs(st[k] - ref) / np.maximum(np.abs(ref), FLOORS[k])
+        if k in BRANCH_TOUCHED:
+            e = np.where(flagged, 0.0, e)
+        assert float(e.max()) < 1e-10, (k, float(e.max()))
+    assert float(np.max(np.abs(ppt - A["ppt"]) / np.maximum(np.abs(A["ppt"]), 1e-12))) < 1e-10

@@ -63,3 +63,26 @@ def test_kid_adapter_first_call(oracle_warm):
                                                    c["exner"], c["dz"], c["qv"], z0, z0, c["hydro"], zh, zh)
     for got, name, floor in ((dth, "katb_dtheta", 1e-6), (dqv, "katb_dqv", 1e-13), (dhy, "katb_dhydro", 1e-13), (ppt, "katb_ppt", 1e-12)):
         assert _rel(np.asarray(got), G[name], floor) < 1e-10, name
+
+
+@pytest.mark.slow
+def test_aerosol_aware_branch_against_its_fixture():
+    """The oracle's aerosol-aware branch (no reference output exists for it) vs its committed vectors."""
+    from oracle.oracle import Oracle
+    from parity import FLOORS
+    A = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_goldens_aero.npz"))
+    o = Oracle(iiwarm=False, aerosol_aware=True)
+    st = {k: A["in_" + k].copy() for k in KEYS}
+    re = o.calc_effectRad(st)
+    for got, name in zip(re, ("re_qc", "re_qi", "re_qs")):
+        assert _rel(got, A[name], 1e-30) < TOL, name
+    ppt, flags = o.batch_step(st, 10.0, want_illcond=True)
+    for k in KEYS:
+        assert _rel(st[k], A["out_" + k], FLOORS.get(k, 1e-300)) < TOL, k
+    assert _rel(ppt, A["ppt"], 1e-12) < TOL and np.array_equal(flags, A["flags"])
+    # and the switch matters: the default context gives other droplet numbers from the same input
+    o2 = Oracle(iiwarm=False)
+    s2 = {k: A["in_" + k].copy() for k in KEYS}
+    o2.batch_step(s2, 10.0)
+    assert not np.array_equal(s2["nc"], A["out_nc"])
+    o.close(); o2.close()
