@@ -146,7 +146,7 @@ KFM_FN double div(double a, double b)
     return std::fma(std::fma(-b, q, a), y, q);
 }
 
-// 1 / b: seed + two Newton steps (<= 1 ulp)
+// 1 / b: seed + one cubically convergent step (<= 1 ulp)
 KFM_FN double rcp(double b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -154,8 +154,8 @@ KFM_FN double rcp(double b)
 #else
     double y = double(1.0f / float(b));
 #endif
-    y = std::fma(std::fma(-b, y, 1.0), y, y);
-    return std::fma(std::fma(-b, y, 1.0), y, y);
+    const double e = std::fma(-b, y, 1.0);               // |e| <= 2**-24.4: y (1 + e + e^2) is good to e^3 = 2**-73
+    return std::fma(y, std::fma(e, e, e), y);            // one cubic step: 3 operations instead of two Newton steps' 4
 }
 
 // ---- the libm entry points the scheme uses, on positive finite normal x / moderate arguments ----

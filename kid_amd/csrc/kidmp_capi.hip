@@ -311,6 +311,7 @@ __global__ void k_math_probe(int fn, int64_t n, const double *x, const double *y
     case 7: r = __builtin_amdgcn_rcp(y[i]); break;                                   // raw v_rcp_f64
     case 8: r = fm::div(x[i], y[i]); break;                                          // the kernel's division
     case 9: r = x[i] / y[i]; break;                                                  // IEEE division (this file is built without -fapprox-func)
+    case 10: r = fm::rcp(y[i]); break;                                               // the kernel's reciprocal
     }
     out[i] = r;
 }
@@ -631,7 +632,7 @@ int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n, const double *qv, c
 int kidmp_math_probe(kidmp_ctx *ctx, int32_t fn, int64_t n, const double *x, const double *y, double *out)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
-    if (n < 0 || !x || !y || !out || fn < 0 || fn > 9) return fail(ctx, KIDMP_EINVAL, "kidmp_math_probe: bad argument");
+    if (n < 0 || !x || !y || !out || fn < 0 || fn > 10) return fail(ctx, KIDMP_EINVAL, "kidmp_math_probe: bad argument");
     if (n == 0) return KIDMP_OK;
     GUARD(ctx);
     double *d = nullptr;

@@ -14,3 +14,5 @@ ref=(a.astype(ld)/b.astype(ld))
 for fn,name in ((8,"fm::div"),(9,"IEEE")):
     q=probe(fn); ulp=np.abs((q.astype(ld)-ref)/ref)/2**-53
     print(name,"max err %.3f ulp(rel 2^-53 units), frac !=IEEE"% float(ulp.max()), float((q!=probe(9)).mean()))
+q=probe(10); ulp=np.abs((q.astype(ld)*b.astype(ld)-1))/2**-53
+print("fm::rcp: max |b*y-1| = %.3f ulp" % float(ulp.max()))
