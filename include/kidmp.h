@@ -205,6 +205,10 @@ int kidmp_cache_read_file(const char *path, int32_t ntab, double *const *tabs, i
 #define KIDMP_MATH_SQRT   4
 #define KIDMP_MATH_CBRT   5
 #define KIDMP_MATH_POW    6
+#define KIDMP_MATH_RCP_SEED 7  /* raw v_rcp_f64(y)                                  */
+#define KIDMP_MATH_DIV    8    /* the kernel's x / y (seed, one Newton step, residual correction) */
+#define KIDMP_MATH_IEEE_DIV 9  /* IEEE x / y, for comparison                        */
+#define KIDMP_MATH_RCP    10   /* the kernel's 1 / y (seed, one cubically convergent step) */
 int kidmp_math_probe(kidmp_ctx *ctx, int32_t fn, int64_t n, const double *x, const double *y, double *out);
 
 /* Seconds spent in table construction during kidmp_init (host wall clock). */

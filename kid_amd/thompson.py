@@ -330,7 +330,7 @@ class ThompsonMP:
         return load_library().kidmp_kernel_fingerprint(self._h).decode()
 
     # ---- introspection for parity tests ----
-    MATH_FUNCS = ("log", "log10", "exp", "exp10", "sqrt", "cbrt", "pow")
+    MATH_FUNCS = ("log", "log10", "exp", "exp10", "sqrt", "cbrt", "pow", "rcp_seed", "div", "ieee_div", "rcp")
 
     def math_probe(self, fn, x, y=None):
         """Evaluate one of the column kernel's fp64 math helpers (csrc/fastmath.h) on the device, elementwise."""

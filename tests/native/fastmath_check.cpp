@@ -20,7 +20,7 @@ int main(int argc, char **argv)
     std::mt19937_64 rng(12345);
     std::uniform_real_distribution<double> U(0., 1.);
     namespace fm = kidmp::fm;
-    double e_sqrt = 0, e_cbrt = 0, e_log = 0, e_log10 = 0, e_exp = 0, e_exp10 = 0, e_pow = 0, e_p10 = 0, e_lm = 0, e_e2 = 0;
+    double e_sqrt = 0, e_cbrt = 0, e_log = 0, e_log10 = 0, e_exp = 0, e_exp10 = 0, e_pow = 0, e_p10 = 0, e_lm = 0, e_e2 = 0, e_div = 0, e_rcp = 0;
     for (long i = 0; i < n; ++i) {
         // positive normal arguments over 1e-45 .. 1e+25 (mixing ratios, numbers, diameters, slopes)
         const double lx = -45. + 70. * U(rng);
@@ -40,12 +40,16 @@ int main(int argc, char **argv)
         e_exp10 = std::fmax(e_exp10, ulp_err(fm::exp10(b), powl(10.L, (long double)b)));
         const double y = -4.2 + 8.4 * U(rng);            // the scheme's exponents lie in (-4.2, 4.2)
         e_pow = std::fmax(e_pow, ulp_err(fm::pow(x, y), powl((long double)x, (long double)y)));
+        // the kernel's own division and reciprocal (host build: a binary32 seed stands in for v_rcp_f64, 2**-23 vs 2**-24.4)
+        const double den = std::pow(10., -30. + 60. * U(rng)) * (1. + U(rng));
+        e_div = std::fmax(e_div, ulp_err(fm::div(x, den), (long double)x / (long double)den));
+        e_rcp = std::fmax(e_rcp, ulp_err(fm::rcp(den), 1.0L / (long double)den));
         const double la = -12. + 24. * U(rng), yb = 3. * U(rng);
         const double xs = std::pow(10., -12. + 12. * U(rng));
         e_p10 = std::fmax(e_p10, ulp_err(fm::pow10_times_pow(la, fm::log2_parts(xs), yb),
                                         powl(10.L, (long double)la) * powl((long double)xs, (long double)yb)));
     }
-    printf("sqrt_pos %.3f\ncbrt_pos %.3f\nln_mant %.3f\nexp2_small %.3f\nlog %.3f\nlog10 %.3f\nexp %.3f\nexp10 %.3f\npow %.3f\npow10_times_pow %.3f\n",
-           e_sqrt, e_cbrt, e_lm, e_e2, e_log, e_log10, e_exp, e_exp10, e_pow, e_p10);
+    printf("sqrt_pos %.3f\ncbrt_pos %.3f\nln_mant %.3f\nexp2_small %.3f\nlog %.3f\nlog10 %.3f\nexp %.3f\nexp10 %.3f\npow %.3f\npow10_times_pow %.3f\ndiv %.3f\nrcp %.3f\n",
+           e_sqrt, e_cbrt, e_lm, e_e2, e_log, e_log10, e_exp, e_exp10, e_pow, e_p10, e_div, e_rcp);
     return 0;
 }

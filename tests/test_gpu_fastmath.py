@@ -53,3 +53,15 @@ def test_pow(gpu_mixed, rng):
     y = rng.uniform(-4.2, 4.2, N)
     want = np.power(x.astype(np.longdouble), y.astype(np.longdouble))
     assert _ulp_err(gpu_mixed.math_probe("pow", x, y), want) <= 4.0
+
+
+def test_division_and_reciprocal(gpu_mixed, rng):
+    """The kernel's own fp64 division (one Newton step + residual correction on a 2^-24.4 seed) and reciprocal (one
+    cubic step): <= 1 ulp, and the quotient equals IEEE division on (practically) every pair."""
+    a, b = _pos(rng, -30, 30), _pos(rng, -30, 30)
+    q = gpu_mixed.math_probe("div", a, b)
+    assert _ulp_err(q, a.astype(np.longdouble) / b.astype(np.longdouble)) <= 1.0
+    assert np.mean(q != gpu_mixed.math_probe("ieee_div", a, b)) < 1e-3
+    assert _ulp_err(gpu_mixed.math_probe("rcp", a, b), 1.0 / b.astype(np.longdouble)) <= 1.0
+    seed = gpu_mixed.math_probe("rcp_seed", a, b)
+    assert float(np.max(np.abs(seed * b - 1.0))) < 2.0 ** -23          # what the step counts rest on
