@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--ncol", type=int, default=0, help="columns per GPU (default: the config's own size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="time the named workload only")
+    ap.add_argument("--no-host-entry", action="store_true", help="skip the PCIe-inclusive leg (kidmp_batch_step_host)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank); gloo only to rehearse N ranks on fewer GPUs")
     ap.add_argument("--arith", default="p64", choices=["p64", "p32n", "f32"],
@@ -138,6 +139,38 @@ def load_pmc_profile(workload, ncol, fingerprint):
         return None
     d["_file"] = os.path.relpath(found[-1], ROOT)
     return d
+
+
+def host_entry_leg(model, st, reps=3):
+    """The PCIe-inclusive rate of the drop-in boundary (kidmp_batch_step_host: the model's arrays live on the host,
+    as in KiD): whole calls timed by the host clock, state in page-locked memory (what the Fortran shim stages
+    through) and in ordinary pageable numpy arrays.  Reported beside the headline, never as `value`."""
+    import time
+    import numpy as np
+    from kid_amd import thompson
+    from kid_amd.thompson import FORCING_NAMES, STATE_NAMES
+    keys = STATE_NAMES + FORCING_NAMES
+    ncol, nz = st["qv"].shape
+    out = {"unit": "column-steps/s", "ncol": ncol,
+           "bytes_in_per_column_step": 14 * nz * 8 + 32, "bytes_out_per_column_step": 12 * nz * 8 + 32,
+           "note": "kidmp_batch_step_host, host clock around whole calls (upload + step + download pipelined over column "
+                   "chunks); w is not uploaded for a non-aerosol context"}
+    for kind in ("pinned", "pageable"):
+        if kind == "pinned":
+            h = {k: thompson.host_pinned_copy(np.ascontiguousarray(st[k])) for k in keys}
+            ppt = thompson.host_empty((ncol, 4)); ppt[...] = 0.0
+        else:
+            h = {k: np.ascontiguousarray(st[k]).copy() for k in keys}
+            ppt = np.zeros((ncol, 4))
+        model.batch_step_host(h, DT, ppt=ppt)                # warm-up: staging ring allocated, pages touched
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model.batch_step_host(h, DT, ppt=ppt)
+        dt = (time.perf_counter() - t0) / reps
+        out[kind] = {"value": ncol / dt, "ms_per_call": dt * 1e3,
+                     "GBps_each_way": [out["bytes_in_per_column_step"] * ncol / dt / 1e9, out["bytes_out_per_column_step"] * ncol / dt / 1e9]}
+        del h, ppt
+    return out
 
 
 def cpu_baseline(model, st, iiwarm, budget_s=12.0, timing=True):
@@ -359,6 +392,8 @@ def run_rank(args):
         args.no_cpu_baseline = args.no_other_workloads = True   # the accuracy leg and the companion workloads are the p64 build's
     if not rehearse and not args.no_cpu_baseline and world == 1:   # N = 1 only: the host cores are shared by the ranks
         out["cpu_baseline"] = cpu_baseline(shard.model, st, res["iiwarm"])
+    if not rehearse and not args.no_host_entry and not args.no_cpu_baseline and world == 1 and args.arith == "p64":
+        out["host_entry"] = host_entry_leg(shard.model, st)
     if not rehearse:
         shard.close()
     del shard, st

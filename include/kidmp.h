@@ -26,6 +26,7 @@
 #ifndef KIDMP_H
 #define KIDMP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -142,6 +143,23 @@ int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt
  * kidmp_batch_step_device grows it on demand, but that allocates (and synchronises the device); after
  * kidmp_reserve, calls with ncol*nz no larger never allocate, so they can be captured into a hipGraph. */
 int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz);
+
+/* ---- host memory for the host-array entries (kidmp_batch_step_host*, kidmp32_batch_step_host) ----
+ * Those entries stand where the reference's `do i=1,nx` loop works on the model's own arrays (W:54-246), so every
+ * call moves the state across PCIe: 14 profiles in, 12 out per column (about 25 KB in binary64).  They run as a
+ * three-stage pipeline over column chunks -- upload of chunk i+1, step of chunk i, download of chunk i-1 on three
+ * streams -- which only overlaps if the DMA engines can reach the host arrays, i.e. if they are page-locked.
+ * kidmp_host_alloc returns page-locked memory (NULL on failure, message in kidmp_last_error(NULL)); free it with
+ * kidmp_host_free.  kidmp_host_register page-locks an existing allocation in place (undo with
+ * kidmp_host_unregister BEFORE freeing it).  Pageable arrays are accepted too: results are the same, the copies
+ * are then staged by the HIP runtime and do not overlap.  None of these four needs a context. */
+void *kidmp_host_alloc(size_t bytes);
+void kidmp_host_free(void *p);
+int kidmp_host_register(void *p, size_t bytes);
+int kidmp_host_unregister(void *p);
+/* Columns per pipeline chunk of this context's host-array entries; 0 (default) = a quarter of the batch, rounded up
+ * to 256, at most 8 192 (one chunk for batches of <= 2048 columns). */
+int kidmp_set_host_chunk(kidmp_ctx *ctx, int64_t ncol_per_chunk);
 
 /* Non-aerosol defaults for nc1d/nwfa1d/nifa1d, which the KiD wrapper leaves
  * unset (W:36): nc=Nt_c/rho, nwfa=11.1e6/rho, nifa=naIN1*0.01/rho with

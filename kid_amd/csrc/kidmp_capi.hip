@@ -21,6 +21,8 @@
 
 using namespace kidmp;
 
+constexpr int HOST_NBUF = 3;
+
 struct kidmp_ctx {
     kidmp_cfg cfg{};
     Consts hc{};
@@ -31,10 +33,14 @@ struct kidmp_ctx {
     bool ready = false;
     double init_s = 0.;
     std::string err;
-    // staging for the host-array entries
+    // staging for the host-array entries: a ring of HOST_NBUF column chunks in HBM, one stream per direction and
+    // one for the kernel, so that the upload of chunk i+1, the step of chunk i and the download of chunk i-1 overlap
     double *d_stage = nullptr;
     size_t stage_bytes = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                    // the context's compute stream
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_up[HOST_NBUF] = {}, ev_step[HOST_NBUF] = {}, ev_down[HOST_NBUF] = {};
+    int64_t host_chunk = 0;                          // columns per chunk; 0 = chosen per call (kidmp_set_host_chunk)
     // [ncol][nz] work profile of the column kernel (StepArgs::scratch), grown on demand
     double *d_scratch = nullptr;
     size_t scratch_elems = 0;
@@ -340,6 +346,90 @@ int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const v
     return KIDMP_OK;
 }
 
+// ---- the host-array entries (kidmp_batch_step_host*, kidmp32_batch_step_host): a three-stage pipeline over column chunks ----
+// The batch is cut into chunks of CH columns; chunk i is uploaded on the context's H2D stream, stepped on its compute
+// stream and downloaded on its D2H stream, through a ring of HOST_NBUF staging sets in HBM, so the two DMA directions
+// (PCIe is full duplex) and the kernel work on three different chunks at once.  Host arrays that are page-locked
+// (kidmp_host_alloc, kidmp_host_register, or the caller's own hipHostMalloc / hipHostRegister) are moved by the DMA
+// engines asynchronously; pageable arrays still work, but the runtime stages them through its own bounce buffer and
+// the calling thread waits for each copy.  Per column-step the boundary moves 14 (15 with w) profiles in and 12 out
+// (+36 for the rate diagnostics): about 25 KB in binary64.
+int64_t pick_host_chunk(const kidmp_ctx *ctx, int64_t ncol)
+{
+    if (ctx->host_chunk > 0) return ctx->host_chunk < ncol ? ctx->host_chunk : ncol;
+    if (ncol <= 2048) return ncol;                            // one chunk: nothing to overlap with
+    int64_t ch = (ncol + 3) / 4;                              // at least four chunks ...
+    ch = (ch + 255) / 256 * 256;
+    return ch > 8192 ? 8192 : ch;                             // ... of at most 8 192 columns (7.9 MB per profile slice; measured optimum)
+}
+
+template <class T, class Launch>
+int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const *io, const T *const *in, T *ppt,
+                  double *rates, int32_t *nstep, Launch launch)
+{
+    const void *ptrs[] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6], io[7], io[8], io[9], io[10], io[11], in[0], in[1], ppt};
+    if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
+    const bool has_w = ctx->cfg.is_aerosol_aware != 0;
+    if (has_w && !in[2] && ncol > 0) return fail(ctx, KIDMP_EINVAL, "kidmp: an aerosol-aware context needs the updraft profile w");
+    if (ncol == 0) return KIDMP_OK;
+    GUARD(ctx);
+    const int64_t CH = pick_host_chunk(ctx, ncol);
+    const int64_t nchunk = (ncol + CH - 1) / CH;
+    const int nbuf = nchunk < HOST_NBUF ? int(nchunk) : HOST_NBUF;
+    const size_t prof = size_t(CH) * size_t(nz);
+    // one staging set: [rates (double)] [15 profiles + ppt (T)] [nstep (int32)], each part 256-byte aligned
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_rates = rates ? up256(size_t(KIDMP_NRATES) * prof * sizeof(double)) : 0;
+    const size_t b_prof = up256(prof * sizeof(T));
+    const size_t b_ppt = up256(4 * size_t(CH) * sizeof(T));
+    const size_t b_nstep = nstep ? up256(4 * size_t(CH) * sizeof(int32_t)) : 0;
+    const size_t b_set = b_rates + 15 * b_prof + b_ppt + b_nstep;
+    const size_t need = b_set * size_t(nbuf);
+    if (need > ctx->stage_bytes) {
+        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+        ctx->d_stage = nullptr;
+        ctx->stage_bytes = 0;
+        HIPTRY(ctx, hipMalloc((void **)&ctx->d_stage, need));
+        ctx->stage_bytes = need;
+    }
+    if (int rc = ensure_scratch(ctx, CH, nz)) return rc;      // before the first launch: growing it later would stall the pipeline
+    char *const base = reinterpret_cast<char *>(ctx->d_stage);
+    for (int64_t i = 0; i < nchunk; ++i) {
+        const int b = int(i % nbuf);
+        const int64_t c0 = i * CH, n = (c0 + CH <= ncol ? CH : ncol - c0);
+        const size_t off = size_t(c0) * size_t(nz), cnt = size_t(n) * size_t(nz);
+        char *set = base + size_t(b) * b_set;
+        double *drates = rates ? reinterpret_cast<double *>(set) : nullptr;
+        T *dio[12]; const T *din[3];
+        char *q = set + b_rates;
+        for (int v = 0; v < 12; ++v) { dio[v] = reinterpret_cast<T *>(q); q += b_prof; }
+        T *dinw[3];
+        for (int v = 0; v < 3; ++v) { dinw[v] = reinterpret_cast<T *>(q); din[v] = dinw[v]; q += b_prof; }
+        T *dppt = reinterpret_cast<T *>(q); q += b_ppt;
+        int32_t *dnstep = nstep ? reinterpret_cast<int32_t *>(q) : nullptr;
+        if (!has_w || !in[2]) din[2] = nullptr;
+        // upload (the set is free once the download of the chunk that used it last has finished)
+        if (i >= nbuf) HIPTRY(ctx, hipStreamWaitEvent(ctx->s_h2d, ctx->ev_down[b], 0));
+        for (int v = 0; v < 12; ++v) HIPTRY(ctx, hipMemcpyAsync(dio[v], io[v] + off, cnt * sizeof(T), hipMemcpyHostToDevice, ctx->s_h2d));
+        for (int v = 0; v < (din[2] ? 3 : 2); ++v) HIPTRY(ctx, hipMemcpyAsync(dinw[v], in[v] + off, cnt * sizeof(T), hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPTRY(ctx, hipMemcpyAsync(dppt, ppt + 4 * c0, 4 * size_t(n) * sizeof(T), hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPTRY(ctx, hipEventRecord(ctx->ev_up[b], ctx->s_h2d));
+        // step
+        HIPTRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[b], 0));
+        if (int rc = launch(n, dio, din, dppt, drates, dnstep)) { (void)hipDeviceSynchronize(); return rc; }
+        HIPTRY(ctx, hipEventRecord(ctx->ev_step[b], ctx->stream));
+        // download
+        HIPTRY(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->ev_step[b], 0));
+        for (int v = 0; v < 12; ++v) HIPTRY(ctx, hipMemcpyAsync(io[v] + off, dio[v], cnt * sizeof(T), hipMemcpyDeviceToHost, ctx->s_d2h));
+        HIPTRY(ctx, hipMemcpyAsync(ppt + 4 * c0, dppt, 4 * size_t(n) * sizeof(T), hipMemcpyDeviceToHost, ctx->s_d2h));
+        if (rates) HIPTRY(ctx, hipMemcpyAsync(rates + size_t(KIDMP_NRATES) * off, drates, size_t(KIDMP_NRATES) * cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->s_d2h));
+        if (nstep) HIPTRY(ctx, hipMemcpyAsync(nstep + 4 * c0, dnstep, 4 * size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_d2h));
+        HIPTRY(ctx, hipEventRecord(ctx->ev_down[b], ctx->s_d2h));
+    }
+    HIPTRY(ctx, hipStreamSynchronize(ctx->s_d2h));
+    return KIDMP_OK;
+}
+
 struct CacheFamily { const char *file; std::vector<double *> dev; int64_t n; };
 std::vector<CacheFamily> cache_families(Tables &t)
 {
@@ -388,6 +478,13 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
     hipError_t e;
 #define INITTRY(x) do { e = (x); if (e != hipSuccess) { g_err = std::string(#x ": ") + hipGetErrorString(e); return bail(KIDMP_EHIP); } } while (0)
     INITTRY(hipStreamCreate(&c->stream));
+    INITTRY(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+    INITTRY(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+    for (int b = 0; b < HOST_NBUF; ++b) {
+        INITTRY(hipEventCreateWithFlags(&c->ev_up[b], hipEventDisableTiming));
+        INITTRY(hipEventCreateWithFlags(&c->ev_step[b], hipEventDisableTiming));
+        INITTRY(hipEventCreateWithFlags(&c->ev_down[b], hipEventDisableTiming));
+    }
     INITTRY(hipMalloc((void **)&c->d_consts, sizeof(Consts)));
     INITTRY(hipMalloc((void **)&c->d_bins, sizeof(Bins)));
     INITTRY(hipMemcpy(c->d_consts, &c->hc, sizeof(Consts), hipMemcpyHostToDevice));
@@ -418,6 +515,13 @@ void kidmp_finalize(kidmp_ctx *c)
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->d_sanity) (void)hipFree(c->d_sanity);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
+    if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
+    for (int b = 0; b < HOST_NBUF; ++b) {
+        if (c->ev_up[b]) (void)hipEventDestroy(c->ev_up[b]);
+        if (c->ev_step[b]) (void)hipEventDestroy(c->ev_step[b]);
+        if (c->ev_down[b]) (void)hipEventDestroy(c->ev_down[b]);
+    }
     give_slot(c->cslot);
     delete c;
 }
@@ -462,6 +566,35 @@ int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
     return ensure_scratch(ctx, ncol, nz);
 }
 
+void *kidmp_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) { g_err = std::string("kidmp_host_alloc: ") + hipGetErrorString(e); return nullptr; }
+    return p;
+}
+void kidmp_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int kidmp_host_register(void *p, size_t bytes)
+{
+    if (!p || !bytes) return fail(nullptr, KIDMP_EINVAL, "kidmp_host_register: null or empty range");
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipfail(nullptr, e, "hipHostRegister"); }
+    return KIDMP_OK;
+}
+int kidmp_host_unregister(void *p)
+{
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipfail(nullptr, e, "hipHostUnregister"); }
+    return KIDMP_OK;
+}
+int kidmp_set_host_chunk(kidmp_ctx *ctx, int64_t ncol_per_chunk)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (ncol_per_chunk < 0) return fail(ctx, KIDMP_EINVAL, "kidmp_set_host_chunk: negative chunk size");
+    ctx->host_chunk = ncol_per_chunk;
+    return KIDMP_OK;
+}
+
 int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
                           double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
                           double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
@@ -478,44 +611,12 @@ int kidmp_batch_step_host_diag(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double 
                                int32_t *nstep)
 {
     double *io[12] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t};
-    const double *in[2] = {p, dz};
-    const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
-    if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
-    if (ncol == 0) return KIDMP_OK;
-    GUARD(ctx);
-    const size_t prof = size_t(ncol) * size_t(nz);
-    const size_t need = (15 * prof + 4 * size_t(ncol) + (rates ? size_t(KIDMP_NRATES) * prof : 0)
-                         + (nstep ? (4 * size_t(ncol) + 1) / 2 : 0)) * sizeof(double);
-    if (need > ctx->stage_bytes) {
-        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
-        ctx->d_stage = nullptr;
-        ctx->stage_bytes = 0;
-        HIPTRY(ctx, hipMalloc((void **)&ctx->d_stage, need));
-        ctx->stage_bytes = need;
-    }
-    double *d = ctx->d_stage;
-    double *dio[12], *din[2];
-    for (int i = 0; i < 12; ++i) { dio[i] = d; d += prof; }
-    for (int i = 0; i < 2; ++i) { din[i] = d; d += prof; }
-    double *dw = d; d += prof;                               // the updraft: only aerosol-aware contexts read it
-    double *dppt = d; d += 4 * size_t(ncol);
-    double *drates = rates ? d : nullptr;
-    if (rates) d += size_t(KIDMP_NRATES) * prof;
-    int32_t *dnstep = nstep ? reinterpret_cast<int32_t *>(d) : nullptr;
-    hipStream_t s = ctx->stream;
-    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(dio[i], io[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
-    for (int i = 0; i < 2; ++i) HIPTRY(ctx, hipMemcpyAsync(din[i], in[i], prof * sizeof(double), hipMemcpyHostToDevice, s));
-    if (ctx->cfg.is_aerosol_aware && w) HIPTRY(ctx, hipMemcpyAsync(dw, w, prof * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPTRY(ctx, hipMemcpyAsync(dppt, ppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyHostToDevice, s));
-    int rc = kidmp_batch_step_device(ctx, ncol, nz, dt, dio[0], dio[1], dio[2], dio[3], dio[4], dio[5], dio[6], dio[7],
-                                     dio[8], dio[9], dio[10], dio[11], din[0], w ? dw : nullptr, din[1], dppt, drates, dnstep, s);
-    if (rc) return rc;
-    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(io[i], dio[i], prof * sizeof(double), hipMemcpyDeviceToHost, s));
-    HIPTRY(ctx, hipMemcpyAsync(ppt, dppt, 4 * size_t(ncol) * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (rates) HIPTRY(ctx, hipMemcpyAsync(rates, drates, size_t(KIDMP_NRATES) * prof * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (nstep) HIPTRY(ctx, hipMemcpyAsync(nstep, dnstep, 4 * size_t(ncol) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIPTRY(ctx, hipStreamSynchronize(s));
-    return KIDMP_OK;
+    const double *in[3] = {p, dz, w};
+    return host_pipeline<double>(ctx, ncol, nz, dt, io, in, ppt, rates, nstep,
+        [&](int64_t n, double *const *d, const double *const *f, double *dppt, double *drates, int32_t *dnstep) {
+            return kidmp_batch_step_device(ctx, n, nz, dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11],
+                                           f[0], f[2], f[1], dppt, drates, dnstep, ctx->stream);
+        });
 }
 
 int kidmp_column_step(kidmp_ctx *ctx, int32_t nz, double dt,
@@ -564,44 +665,13 @@ int kidmp32_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt,
                             int32_t *nstep, int32_t arith)
 {
     float *io[12] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t};
-    const float *in[2] = {p, dz};
-    const void *ptrs[] = {qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, dz, ppt};
-    if (int rc = check_step_args(ctx, ncol, nz, double(dt), ptrs, 15)) return rc;
-    if (ncol == 0) return KIDMP_OK;
-    GUARD(ctx);
-    const size_t prof = size_t(ncol) * size_t(nz);
-    const size_t need = (15 * prof + 4 * size_t(ncol)) * sizeof(float) + (rates ? size_t(KIDMP_NRATES) * prof : 0) * sizeof(double)
-                        + (nstep ? 4 * size_t(ncol) * sizeof(int32_t) : 0) + 64;
-    if (need > ctx->stage_bytes) {
-        if (ctx->d_stage) (void)hipFree(ctx->d_stage);
-        ctx->d_stage = nullptr;
-        ctx->stage_bytes = 0;
-        HIPTRY(ctx, hipMalloc((void **)&ctx->d_stage, need));
-        ctx->stage_bytes = need;
-    }
-    // layout: [rates (double)] [14 profiles + ppt (float)] [nstep (int32)] -- the doubles first, for alignment
-    double *drates = rates ? ctx->d_stage : nullptr;
-    float *d = reinterpret_cast<float *>(ctx->d_stage + (rates ? size_t(KIDMP_NRATES) * prof : 0));
-    float *dio[12], *din[2];
-    for (int i = 0; i < 12; ++i) { dio[i] = d; d += prof; }
-    for (int i = 0; i < 2; ++i) { din[i] = d; d += prof; }
-    float *dw = d; d += prof;
-    float *dppt = d; d += 4 * size_t(ncol);
-    int32_t *dnstep = nstep ? reinterpret_cast<int32_t *>(d) : nullptr;
-    hipStream_t s = ctx->stream;
-    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(dio[i], io[i], prof * sizeof(float), hipMemcpyHostToDevice, s));
-    for (int i = 0; i < 2; ++i) HIPTRY(ctx, hipMemcpyAsync(din[i], in[i], prof * sizeof(float), hipMemcpyHostToDevice, s));
-    if (ctx->cfg.is_aerosol_aware && w) HIPTRY(ctx, hipMemcpyAsync(dw, w, prof * sizeof(float), hipMemcpyHostToDevice, s));
-    HIPTRY(ctx, hipMemcpyAsync(dppt, ppt, 4 * size_t(ncol) * sizeof(float), hipMemcpyHostToDevice, s));
-    int rc = kidmp32_batch_step_device(ctx, ncol, nz, dt, dio[0], dio[1], dio[2], dio[3], dio[4], dio[5], dio[6], dio[7],
-                                       dio[8], dio[9], dio[10], dio[11], din[0], w ? dw : nullptr, din[1], dppt, drates, dnstep, arith, s);
-    if (rc) return rc;
-    for (int i = 0; i < 12; ++i) HIPTRY(ctx, hipMemcpyAsync(io[i], dio[i], prof * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIPTRY(ctx, hipMemcpyAsync(ppt, dppt, 4 * size_t(ncol) * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (rates) HIPTRY(ctx, hipMemcpyAsync(rates, drates, size_t(KIDMP_NRATES) * prof * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (nstep) HIPTRY(ctx, hipMemcpyAsync(nstep, dnstep, 4 * size_t(ncol) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIPTRY(ctx, hipStreamSynchronize(s));
-    return KIDMP_OK;
+    const float *in[3] = {p, dz, w};
+    if (arith != KIDMP_ARITH_P32N && arith != KIDMP_ARITH_F32) return fail(ctx, KIDMP_EINVAL, "kidmp32: arith must be KIDMP_ARITH_P32N or KIDMP_ARITH_F32");
+    return host_pipeline<float>(ctx, ncol, nz, double(dt), io, in, ppt, rates, nstep,
+        [&](int64_t n, float *const *d, const float *const *f, float *dppt, double *drates, int32_t *dnstep) {
+            return kidmp32_batch_step_device(ctx, n, nz, dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11],
+                                             f[0], f[2], f[1], dppt, drates, dnstep, arith, ctx->stream);
+        });
 }
 
 int kidmp32_column_step(kidmp_ctx *ctx, int32_t nz, float dt,

@@ -63,6 +63,11 @@ module module_mp_thompson09n
   end type kidmp_cfg
 
   type(c_ptr), save :: ctx = c_null_ptr
+  ! Staging arrays of mp_thompson_batch: page-locked (kidmp_host_alloc) and kept between calls, so that the library's
+  ! upload / step / download pipeline can move them by DMA.  1 = state (12 profiles), 2 = p, w, dz, 3 = ppt,
+  ! 4 = the 36 rate profiles, 5 = the substep counts.
+  type(c_ptr), save :: hbuf(5) = c_null_ptr
+  integer(c_size_t), save :: hbytes(5) = 0_c_size_t
 
   interface
      integer(c_int) function kidmp_init(cfg, ctx_out) bind(C, name='kidmp_init')
@@ -91,6 +96,14 @@ module module_mp_thompson09n
        real(c_double), intent(in) :: p(*), w(*), dz(*)
        type(c_ptr), value :: rates, nstep            ! NULL, or [ncol][36][nz] doubles / [ncol][4] int32
      end function kidmp_batch_step_host_diag
+     type(c_ptr) function kidmp_host_alloc(bytes) bind(C, name='kidmp_host_alloc')   ! page-locked host memory
+       import :: c_ptr, c_size_t
+       integer(c_size_t), value :: bytes
+     end function kidmp_host_alloc
+     subroutine kidmp_host_free(p) bind(C, name='kidmp_host_free')
+       import :: c_ptr
+       type(c_ptr), value :: p
+     end subroutine kidmp_host_free
      integer(c_int) function kidmp32_batch_step_host(ctx, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, &
           nc, nwfa, nifa, t, p, w, dz, ppt, rates, nstep, arith) bind(C, name='kidmp32_batch_step_host')
        import :: c_int, c_int32_t, c_int64_t, c_float, c_ptr
@@ -127,6 +140,20 @@ contains
     stop 1      ! the reference aborts on init failure too (Fortran runtime error at M:3718)
   end subroutine stop_on_error
 
+  ! hbuf(i) with room for `need` bytes (grown, never shrunk)
+  subroutine staging(i, need)
+    integer, intent(in) :: i
+    integer(c_size_t), intent(in) :: need
+    if (need <= hbytes(i) .and. c_associated(hbuf(i))) return
+    if (c_associated(hbuf(i))) call kidmp_host_free(hbuf(i))
+    hbuf(i) = kidmp_host_alloc(need)
+    hbytes(i) = need
+    if (.not. c_associated(hbuf(i))) then
+       write(*,'(a,i0,a)') ' module_mp_thompson09n: kidmp_host_alloc(', need, ') failed'
+       stop 1
+    end if
+  end subroutine staging
+
   ! thompson_init, M:374-797: constants on the host, lookup tables built on the GPU.
   subroutine thompson_init
     type(kidmp_cfg) :: cfg
@@ -146,6 +173,11 @@ contains
   end subroutine thompson_init
 
   subroutine thompson_finalize
+    integer :: i
+    do i = 1, 5
+       if (c_associated(hbuf(i))) call kidmp_host_free(hbuf(i))
+       hbuf(i) = c_null_ptr;  hbytes(i) = 0_c_size_t
+    end do
     if (c_associated(ctx)) call kidmp_finalize(ctx)
     ctx = c_null_ptr
   end subroutine thompson_finalize
@@ -179,18 +211,23 @@ contains
     real, dimension(nz,ncol), intent(inout) :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t
     real, dimension(nz,ncol), intent(in) :: p, w, dz
     real, dimension(4,ncol), intent(inout) :: ppt
-    real(c_double), allocatable, target :: s(:,:,:), f(:,:,:), pp(:,:), rates(:,:,:)
-    real(c_float), allocatable :: s4(:,:,:), f4(:,:,:), pp4(:,:)
-    integer(c_int32_t), allocatable, target :: nstep(:,:)
+    real(c_double), pointer :: s(:,:,:), f(:,:,:), pp(:,:), rates(:,:,:)
+    real(c_float), pointer :: s4(:,:,:), f4(:,:,:), pp4(:,:)
+    integer(c_int32_t), pointer :: nstep(:,:)
     type(c_ptr) :: prates, pnstep
+    integer(c_size_t) :: nprof
     integer(c_int) :: rc
     integer(c_int32_t) :: arith
     integer :: i, k, r, r0
     if (.not. c_associated(ctx)) call thompson_init
     prates = c_null_ptr;  pnstep = c_null_ptr
+    nprof = int(nz, c_size_t) * int(ncol, c_size_t)
     if (l_rate_diagnostics) then
-       allocate(rates(nz,NRATES,ncol), nstep(4,ncol))       ! the C ABI's [ncol][36][nz] / [ncol][4]
-       prates = c_loc(rates);  pnstep = c_loc(nstep)
+       call staging(4, 8_c_size_t * NRATES * nprof)
+       call staging(5, 16_c_size_t * ncol)
+       call c_f_pointer(hbuf(4), rates, [nz, NRATES, ncol])  ! the C ABI's [ncol][36][nz] / [ncol][4]
+       call c_f_pointer(hbuf(5), nstep, [4, ncol])
+       prates = hbuf(4);  pnstep = hbuf(5)
     end if
     if (trim(kidmp_arith) /= 'p64') then
        ! ---- binary32 state straight to the GPU: the reference's own REAL / DOUBLE PRECISION split, or all binary32 ----
@@ -200,7 +237,8 @@ contains
        end if
        arith = 0_c_int32_t
        if (trim(kidmp_arith) == 'f32') arith = 1_c_int32_t
-       allocate(s4(nz,ncol,12), f4(nz,ncol,3), pp4(4,ncol))
+       call staging(1, 4_c_size_t * 12 * nprof);  call staging(2, 4_c_size_t * 3 * nprof);  call staging(3, 16_c_size_t * ncol)
+       call c_f_pointer(hbuf(1), s4, [nz, ncol, 12]);  call c_f_pointer(hbuf(2), f4, [nz, ncol, 3]);  call c_f_pointer(hbuf(3), pp4, [4, ncol])
        s4(:,:,1) = qv;  s4(:,:,2) = qc;  s4(:,:,3) = qi;   s4(:,:,4) = qr
        s4(:,:,5) = qs;  s4(:,:,6) = qg;  s4(:,:,7) = ni;   s4(:,:,8) = nr
        s4(:,:,9) = nc;  s4(:,:,10) = nwfa; s4(:,:,11) = nifa; s4(:,:,12) = t
@@ -214,9 +252,9 @@ contains
        qs = s4(:,:,5);  qg = s4(:,:,6);  ni = s4(:,:,7);   nr = s4(:,:,8)
        nc = s4(:,:,9);  nwfa = s4(:,:,10); nifa = s4(:,:,11); t = s4(:,:,12)
        ppt = pp4
-       deallocate(s4, f4, pp4)
     else
-    allocate(s(nz,ncol,12), f(nz,ncol,3), pp(4,ncol))
+    call staging(1, 8_c_size_t * 12 * nprof);  call staging(2, 8_c_size_t * 3 * nprof);  call staging(3, 32_c_size_t * ncol)
+    call c_f_pointer(hbuf(1), s, [nz, ncol, 12]);  call c_f_pointer(hbuf(2), f, [nz, ncol, 3]);  call c_f_pointer(hbuf(3), pp, [4, ncol])
     s(:,:,1) = qv;  s(:,:,2) = qc;  s(:,:,3) = qi;   s(:,:,4) = qr
     s(:,:,5) = qs;  s(:,:,6) = qg;  s(:,:,7) = ni;   s(:,:,8) = nr
     s(:,:,9) = nc;  s(:,:,10) = nwfa; s(:,:,11) = nifa; s(:,:,12) = t
@@ -230,7 +268,6 @@ contains
     qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7);   nr = s(:,:,8)
     nc = s(:,:,9);  nwfa = s(:,:,10); nifa = s(:,:,11); t = s(:,:,12)
     ppt = pp
-    deallocate(s, f, pp)
     end if
     ! ---- the KiD block of M:2962-3124: per column, per level, 30 mixed-phase rates (.not. iiwarm) then 6 warm
     !      ones; save_dg(k, value, ...) when nx == 1, save_dg(k, ii, value, ...) otherwise; a column that left
@@ -250,7 +287,6 @@ contains
              end do
           end do
        end do
-       deallocate(rates, nstep)
     end if
   end subroutine mp_thompson_batch
 

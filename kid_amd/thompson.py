@@ -110,6 +110,16 @@ def load_library(path=None):
     L.kidmp_cache_write_file.argtypes = [C.c_char_p, C.c_int32, C.POINTER(_dp), C.c_int64]
     L.kidmp_cache_read_file.restype = C.c_int
     L.kidmp_cache_read_file.argtypes = [C.c_char_p, C.c_int32, C.POINTER(_dp), C.c_int64]
+    L.kidmp_host_alloc.restype = _vp
+    L.kidmp_host_alloc.argtypes = [C.c_size_t]
+    L.kidmp_host_free.restype = None
+    L.kidmp_host_free.argtypes = [_vp]
+    L.kidmp_host_register.restype = C.c_int
+    L.kidmp_host_register.argtypes = [_vp, C.c_size_t]
+    L.kidmp_host_unregister.restype = C.c_int
+    L.kidmp_host_unregister.argtypes = [_vp]
+    L.kidmp_set_host_chunk.restype = C.c_int
+    L.kidmp_set_host_chunk.argtypes = [_vp, C.c_int64]
     L.kidmp_init_seconds.restype = C.c_double
     L.kidmp_init_seconds.argtypes = [_vp]
     L.kidmp_kernel_name.restype = C.c_char_p
@@ -120,6 +130,38 @@ def load_library(path=None):
 
 def _np_ptr(a):
     return a.ctypes.data_as(_dp)
+
+
+class _PinnedBlock:
+    """Owner of one kidmp_host_alloc block.  numpy arrays made from it (and their views) hold it as their base,
+    so the block is freed when the last of them goes away."""
+
+    def __init__(self, nbytes):
+        self.nbytes = max(int(nbytes), 1)
+        self.ptr = load_library().kidmp_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise KidmpError("kidmp_host_alloc(%d) failed: %s" % (nbytes, load_library().kidmp_last_error(None).decode()))
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        if getattr(self, "ptr", None) and _lib is not None:
+            _lib.kidmp_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_empty(shape, dtype=np.float64):
+    """numpy array in page-locked host memory (kidmp_host_alloc): what the host-array entries can move by DMA."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    raw = np.asarray(_PinnedBlock(n * dtype.itemsize))       # base = the block
+    return raw[: n * dtype.itemsize].view(dtype).reshape(shape)
+
+
+def host_pinned_copy(a):
+    """A page-locked copy of a numpy array."""
+    b = host_empty(a.shape, a.dtype)
+    b[...] = a
+    return b
 
 
 class ThompsonMP:
@@ -270,6 +312,10 @@ class ThompsonMP:
             self._h, qv.numel(), qv.data_ptr(), t.data_ptr(), p.data_ptr(), nc.data_ptr(), nwfa.data_ptr(),
             nifa.data_ptr(), s))
         return nc, nwfa, nifa
+
+    def set_host_chunk(self, ncol_per_chunk):
+        """Columns per pipeline chunk of the host-array entries (0 = default)."""
+        self._check(load_library().kidmp_set_host_chunk(self._h, int(ncol_per_chunk)))
 
     def reserve(self, ncol, nz):
         """Pre-size the context's work buffer: later batch_step calls of that size never allocate (graph capture)."""

@@ -1,0 +1,150 @@
+"""The host-array entries (kidmp_batch_step_host*, kidmp32_batch_step_host) as a chunked upload / step / download
+pipeline (-m gpu): whatever the chunking and whatever kind of host memory, they must return bit for bit what the
+device-resident entry returns for the same columns -- columns are independent, so cutting the batch changes nothing."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from kid_amd import thompson
+from kid_amd.thompson import NRATES, STATE_NAMES, FORCING_NAMES
+
+pytestmark = pytest.mark.gpu
+KEYS = STATE_NAMES + FORCING_NAMES
+
+
+def _device_reference(m, st, dt, want_rates):
+    dev = torch.device("cuda", 0)
+    d = {k: torch.as_tensor(st[k]).to(dev) for k in KEYS}
+    ncol, nz = st["qv"].shape
+    ppt = torch.zeros(ncol, 4, dtype=torch.float64, device=dev)
+    rates = torch.zeros(ncol, NRATES, nz, dtype=torch.float64, device=dev) if want_rates else None
+    nstep = torch.zeros(ncol, 4, dtype=torch.int32, device=dev)
+    m.batch_step(d, dt, ppt, rates=rates, nstep=nstep)
+    torch.cuda.synchronize()
+    return ({k: d[k].cpu().numpy() for k in STATE_NAMES}, ppt.cpu().numpy(),
+            rates.cpu().numpy() if want_rates else None, nstep.cpu().numpy())
+
+
+def _state(name, ncol):
+    st = cases.config3(ncol, seed=cases.SEED + 7) if name == "mixed" else cases.config2(ncol)
+    if name == "warm":                                       # replicated columns: make them differ
+        rng = np.random.default_rng(5)
+        st["qr"] = st["qr"] * rng.uniform(0.5, 2.0, size=(ncol, 1))
+    return {k: np.ascontiguousarray(st[k]) for k in KEYS}
+
+
+@pytest.mark.parametrize("kind", ["pageable", "pinned", "registered"])
+@pytest.mark.parametrize("name,chunk", [("mixed", 0), ("mixed", 1024), ("mixed", 700), ("warm", 256)])
+def test_host_entry_equals_device_entry(gpu_mixed, gpu_warm, name, chunk, kind):
+    m = gpu_mixed if name == "mixed" else gpu_warm
+    ncol = 4500                                              # default chunking: 4 chunks of 1280, the last one ragged
+    st = _state(name, ncol)
+    ref, ref_ppt, _, _ = _device_reference(m, st, 10.0, False)
+    if kind == "pinned":
+        got = {k: thompson.host_pinned_copy(st[k]) for k in KEYS}
+        ppt = thompson.host_empty((ncol, 4)); ppt[...] = 0.0
+    else:
+        got = {k: st[k].copy() for k in KEYS}
+        ppt = np.zeros((ncol, 4))
+    L = thompson.load_library()
+    if kind == "registered":
+        for k in KEYS:
+            assert L.kidmp_host_register(got[k].ctypes.data_as(C.c_void_p), got[k].nbytes) == 0
+    try:
+        m.set_host_chunk(chunk)
+        m.batch_step_host(got, 10.0, ppt=ppt)
+    finally:
+        m.set_host_chunk(0)
+        if kind == "registered":
+            for k in KEYS:
+                assert L.kidmp_host_unregister(got[k].ctypes.data_as(C.c_void_p)) == 0
+    for k in STATE_NAMES:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(ppt, ref_ppt)
+    for k in FORCING_NAMES:
+        assert np.array_equal(got[k], st[k]), k              # inputs untouched
+
+
+def test_host_entry_rates_and_substeps_through_the_pipeline(gpu_mixed):
+    ncol = 3000
+    st = _state("mixed", ncol)
+    ref, ref_ppt, ref_rates, ref_nstep = _device_reference(gpu_mixed, st, 10.0, True)
+    L = thompson.load_library()
+    got = {k: thompson.host_pinned_copy(st[k]) for k in KEYS}
+    ppt = thompson.host_empty((ncol, 4)); ppt[...] = 0.0
+    rates = thompson.host_empty((ncol, NRATES, 120)); rates[...] = -1.0
+    nstep = thompson.host_empty((ncol, 4), np.int32); nstep[...] = -1
+    dp = C.POINTER(C.c_double)
+    gpu_mixed.set_host_chunk(512)                            # 6 chunks, the last one of 440 columns; the ring wraps twice
+    try:
+        rc = L.kidmp_batch_step_host_diag(gpu_mixed._h, C.c_int64(ncol), C.c_int32(120), C.c_double(10.0),
+                                          *[got[k].ctypes.data_as(dp) for k in KEYS],
+                                          ppt.ctypes.data_as(dp), rates.ctypes.data_as(dp),
+                                          nstep.ctypes.data_as(C.POINTER(C.c_int32)))
+    finally:
+        gpu_mixed.set_host_chunk(0)
+    assert rc == 0
+    for k in STATE_NAMES:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(ppt, ref_ppt)
+    assert np.array_equal(rates, ref_rates)
+    assert np.array_equal(nstep, ref_nstep)
+
+
+def test_host_entry_accumulates_ppt_and_repeats(gpu_warm):
+    """ppt is INOUT (M:1172): two calls through the pipeline accumulate like two calls of the device entry."""
+    ncol = 2500
+    st = _state("warm", ncol)
+    dev = torch.device("cuda", 0)
+    d = {k: torch.as_tensor(st[k]).to(dev) for k in KEYS}
+    dppt = torch.zeros(ncol, 4, dtype=torch.float64, device=dev)
+    got = {k: thompson.host_pinned_copy(st[k]) for k in KEYS}
+    ppt = thompson.host_empty((ncol, 4)); ppt[...] = 0.0
+    for _ in range(3):
+        gpu_warm.batch_step(d, 10.0, dppt)
+        gpu_warm.batch_step_host(got, 10.0, ppt=ppt)
+    torch.cuda.synchronize()
+    for k in STATE_NAMES:
+        assert np.array_equal(got[k], d[k].cpu().numpy()), k
+    assert np.array_equal(ppt, dppt.cpu().numpy())
+    assert ppt[:, 0].sum() > 0.0
+
+
+def test_binary32_host_entry_through_the_pipeline(gpu_mixed):
+    ncol = 2600
+    st = {k: v.astype(np.float32) for k, v in _state("mixed", ncol).items()}
+    dev = torch.device("cuda", 0)
+    d = {k: torch.as_tensor(st[k]).to(dev) for k in KEYS}
+    dppt = torch.zeros(ncol, 4, dtype=torch.float32, device=dev)
+    gpu_mixed.batch_step32(d, 10.0, dppt, arith="p32n")
+    torch.cuda.synchronize()
+    got = {k: thompson.host_pinned_copy(st[k]) for k in KEYS}
+    gpu_mixed.set_host_chunk(1000)
+    try:
+        ppt, _, nstep = gpu_mixed.batch_step32_host(got, 10.0, arith="p32n", want_nstep=True)
+    finally:
+        gpu_mixed.set_host_chunk(0)
+    for k in STATE_NAMES:
+        assert np.array_equal(got[k], d[k].cpu().numpy()), k
+    assert np.array_equal(ppt, dppt.cpu().numpy())
+    assert (nstep >= 0).all() and nstep.max() >= 1
+
+
+def test_pinned_block_outlives_its_first_view():
+    a = thompson.host_empty((8, 16))
+    a[...] = 3.0
+    row = a[2]
+    del a
+    import gc
+    gc.collect()
+    assert row.sum() == 48.0                                 # the block is still alive: the view holds it
+
+
+def test_host_chunk_argument_checks(gpu_mixed):
+    L = thompson.load_library()
+    assert L.kidmp_set_host_chunk(gpu_mixed._h, -1) != 0
+    assert L.kidmp_set_host_chunk(None, 16) != 0
+    assert L.kidmp_host_register(None, 16) != 0
