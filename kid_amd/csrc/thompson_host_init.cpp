@@ -145,6 +145,18 @@ void host_init(int iiwarm, int l_sediment, double set_Nc, Consts &c, Bins &b)
     c.lamr_exp_fac = std::pow(c.crg[2] * c.org2 * c.org1, bm_r);
     c.lamg_exp_fac = std::pow(c.cgg[2] * c.ogg2 * c.ogg1, bm_g);
     for (int n = 0; n < 15; ++n) c.dcg_fac[n] = std::pow(c.ccg[2][n] * c.ocg2[n], c.obmr);
+    for (int i = 0; i < 16; ++i) {
+        const int n = i < 15 ? i : 14;
+        c.lds_tab[0 * 16 + i] = c.ccg[0][n];  c.lds_tab[1 * 16 + i] = c.ccg[1][n];  c.lds_tab[2 * 16 + i] = c.ocg1[n];
+        c.lds_tab[3 * 16 + i] = c.ocg2[n];    c.lds_tab[4 * 16 + i] = c.cce[1][n];  c.lds_tab[5 * 16 + i] = c.dcg_fac[n];
+    }
+    for (int t = 0; t < 32; ++t) {
+        const int n = t - 16, m = n < 0 ? -n : n;
+        static const double sq[5] = {10., 100., 1.e4, 1.e8, 1.e16};
+        double T = 1.;                                        // 10**m, exact (m <= 16): every partial product is a power of ten
+        for (int b = 0; b < 5; ++b) if (m & (1 << b)) T *= sq[b];
+        c.lds_tab[96 + t] = n <= 0 ? T : 1. / T;
+    }
 
     // axes, M:215-315
     decade_axis(b.r_c, ntb_c, -6);

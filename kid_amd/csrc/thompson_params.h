@@ -76,6 +76,11 @@ struct Consts {
     // droplet-number axis of tnc_wev (aerosol-aware droplet evaporation, M:2828): t_Nc(1) and the INTEGER nic1 of M:670
     double t_Nc1;
     int32_t nic1, pad_;
+    // what the column kernel copies into LDS at workgroup start, as one flat table (one load per thread):
+    // [0..95]   six rows of 16 indexed by nu_c-1 (entry 15 repeats 14): ccg(1,:), ccg(2,:), ocg1, ocg2, cce(2,:), dcg_fac
+    // [96..127] 10**-n for n = -16 .. 15: the decade finder's scale factors (exact powers of ten, or their
+    //           correctly rounded reciprocals)
+    double lds_tab[128];
 };
 
 // bins and axes needed only while building tables (device copies)
