@@ -139,9 +139,9 @@ int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt
                               float *ppt, double *rates, int32_t *nstep,
                               int32_t arith, void *stream);
 
-/* Sizes the context's internal work buffer for batches of up to ncol columns of nz levels.  Optional:
- * kidmp_batch_step_device grows it on demand, but that allocates (and synchronises the device); after
- * kidmp_reserve, calls with ncol*nz no larger never allocate, so they can be captured into a hipGraph. */
+/* Kept for callers of earlier builds: checks its arguments and returns KIDMP_OK.  The device entries own no
+ * per-batch device memory (round 1's work profile now lives in LDS): they never allocate, so they can be captured
+ * into a hipGraph as they are, and one context may have launches in flight on several streams. */
 int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz);
 
 /* ---- host memory for the host-array entries (kidmp_batch_step_host*, kidmp32_batch_step_host) ----

@@ -41,9 +41,6 @@ struct kidmp_ctx {
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     hipEvent_t ev_up[HOST_NBUF] = {}, ev_step[HOST_NBUF] = {}, ev_down[HOST_NBUF] = {};
     int64_t host_chunk = 0;                          // columns per chunk; 0 = chosen per call (kidmp_set_host_chunk)
-    // [ncol][nz] work profile of the column kernel (StepArgs::scratch), grown on demand
-    double *d_scratch = nullptr;
-    size_t scratch_elems = 0;
     int debug_stop = 0;
     int cslot = -1;
     // partial sums of kidmp_reduce_rates_device, accumulators of kidmp_sanity_device
@@ -322,19 +319,6 @@ __global__ void k_math_probe(int fn, int64_t n, const double *x, const double *y
     out[i] = r;
 }
 
-// the [ncol][nz] work profile of the column kernel; grows, never shrinks
-int ensure_scratch(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
-{
-    const size_t need = size_t(ncol) * size_t(nz);
-    if (need <= ctx->scratch_elems) return KIDMP_OK;
-    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);  // hipFree waits for launches still using the old buffer
-    ctx->d_scratch = nullptr;
-    ctx->scratch_elems = 0;
-    HIPTRY(ctx, hipMalloc((void **)&ctx->d_scratch, need * sizeof(double)));
-    ctx->scratch_elems = need;
-    return KIDMP_OK;
-}
-
 int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const void *const *ptrs, int nptr)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
@@ -392,7 +376,6 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
         HIPTRY(ctx, hipMalloc((void **)&ctx->d_stage, need));
         ctx->stage_bytes = need;
     }
-    if (int rc = ensure_scratch(ctx, CH, nz)) return rc;      // before the first launch: growing it later would stall the pipeline
     char *const base = reinterpret_cast<char *>(ctx->d_stage);
     for (int64_t i = 0; i < nchunk; ++i) {
         const int b = int(i % nbuf);
@@ -511,7 +494,6 @@ void kidmp_finalize(kidmp_ctx *c)
     if (c->d_consts) (void)hipFree(c->d_consts);
     if (c->d_bins) (void)hipFree(c->d_bins);
     if (c->d_stage) (void)hipFree(c->d_stage);
-    if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->d_sanity) (void)hipFree(c->d_sanity);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -552,8 +534,6 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     a.ncol = ncol; a.nz = nz; a.dt = dt;
     a.debug_stop = ctx->debug_stop;
     if (ncol == 0) return KIDMP_OK;
-    if (int rc = ensure_scratch(ctx, ncol, nz)) return rc;
-    a.scratch = ctx->d_scratch;
     HIPTRY(ctx, p64::launch_column_step(a, (hipStream_t)stream));
     return KIDMP_OK;
 }
@@ -562,8 +542,7 @@ int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
     if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return fail(ctx, KIDMP_EINVAL, "kidmp_reserve: bad argument");
-    GUARD(ctx);
-    return ensure_scratch(ctx, ncol, nz);
+    return KIDMP_OK;                                         // the column step owns no per-batch device memory any more
 }
 
 void *kidmp_host_alloc(size_t bytes)
@@ -651,8 +630,6 @@ int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt
     a.ncol = ncol; a.nz = nz; a.dt = dt;
     a.debug_stop = ctx->debug_stop;
     if (ncol == 0) return KIDMP_OK;
-    if (int rc = ensure_scratch(ctx, ncol, nz)) return rc;
-    a.scratch = reinterpret_cast<float *>(ctx->d_scratch);
     if (arith == KIDMP_ARITH_P32N) HIPTRY(ctx, p32n::launch_column_step(a, (hipStream_t)stream));
     else                           HIPTRY(ctx, f32::launch_column_step(a, (hipStream_t)stream));
     return KIDMP_OK;

@@ -21,7 +21,6 @@ struct StepArgsT {
     R *ppt;               // [ncol][4] rain, snow, graupel, ice (accumulated, M:1172)
     double *rates;        // nullptr or [ncol][36][nz] (binary64 in every variant: the rates are DOUBLE PRECISION)
     int32_t *nstep;       // nullptr or [ncol][4] rain, ice, snow, graupel
-    R *scratch;           // [ncol][nz] work profile owned by the context (block-K rain mvd, pass 1 -> pass 3)
     int32_t cslot;        // slot of this context's Consts in constant memory (upload_consts)
     int32_t iiwarm;       // the context's iiwarm switch: selects the warm-rain instantiation of the kernel
     int32_t aero;         // the context's is_aerosol_aware switch (M:28): selects the aerosol-aware instantiation
