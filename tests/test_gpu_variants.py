@@ -124,29 +124,57 @@ def test_workgroup_remainders_and_dry_columns(gpu_mixed, oracle_mixed, ncol):
 
 
 def test_hip_graph_capture_of_steps(gpu_mixed):
-    """After reserve() the device entry allocates nothing, so K steps can be captured into a HIP graph and replayed;
-    the replay gives the same bits as K eager launches."""
+    """The device entry never allocates (no per-batch work buffer), so K steps of a batch size the context has never
+    seen can be captured into a HIP graph and replayed; the replay gives the same bits as K eager launches."""
     import torch
-    st = cases.config3(64)
-    gpu_mixed.reserve(64, 120)
-    eager = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
-    ppt_e = torch.zeros(64, 4, dtype=torch.float64, device="cuda")
-    for _ in range(3):
-        gpu_mixed.batch_step(eager, 10.0, ppt_e)
+    st = cases.config3(72)                                   # no other test steps 72 columns
     graphed = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
-    ppt_g = torch.zeros(64, 4, dtype=torch.float64, device="cuda")
+    ppt_g = torch.zeros(72, 4, dtype=torch.float64, device="cuda")
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g):                                # the very first launches of this size are the captured ones
         for _ in range(3):
             gpu_mixed.batch_step(graphed, 10.0, ppt_g)
     for k in graphed:                                                  # capture does not execute: state still initial
         assert torch.equal(graphed[k].cpu(), torch.from_numpy(st[k]))
     g.replay()
     torch.cuda.synchronize()
+    eager = {k: torch.from_numpy(v).cuda() for k, v in st.items()}
+    ppt_e = torch.zeros(72, 4, dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        gpu_mixed.batch_step(eager, 10.0, ppt_e)
+    torch.cuda.synchronize()
     for k in cases.KEYS:
         assert torch.equal(graphed[k], eager[k]), k
     assert torch.equal(ppt_g, ppt_e)
+
+
+def test_one_context_steps_on_two_streams_at_once(gpu_mixed):
+    """No context-owned work buffer: two batches stepped concurrently on two streams through ONE context end exactly
+    where they end when stepped one after the other."""
+    import torch
+    a0, b0 = cases.config3(3000, seed=cases.SEED + 21), cases.config5(3000, seed=cases.SEED + 22)
+
+    def run(concurrent):
+        A = {k: torch.from_numpy(v).cuda() for k, v in a0.items()}
+        B = {k: torch.from_numpy(v).cuda() for k, v in b0.items()}
+        pa = torch.zeros(3000, 4, dtype=torch.float64, device="cuda")
+        pb = torch.zeros(3000, 4, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        s1, s2 = (torch.cuda.Stream(), torch.cuda.Stream()) if concurrent else (torch.cuda.current_stream(),) * 2
+        for _ in range(4):
+            with torch.cuda.stream(s1):
+                gpu_mixed.batch_step(A, 10.0, pa)
+            with torch.cuda.stream(s2):
+                gpu_mixed.batch_step(B, 10.0, pb)
+        torch.cuda.synchronize()
+        return A, B, pa, pb
+
+    A1, B1, pa1, pb1 = run(False)
+    A2, B2, pa2, pb2 = run(True)
+    for k in cases.KEYS:
+        assert torch.equal(A1[k], A2[k]) and torch.equal(B1[k], B2[k]), k
+    assert torch.equal(pa1, pa2) and torch.equal(pb1, pb2)
 
 
 def test_c_abi_argument_checks_binary32_and_diagnostics(gpu_mixed):
