@@ -344,6 +344,7 @@ def run_rank(args):
         prof = load_pmc_profile(res["name"], ncol, fp)
         out = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "frac": achieved / HBM_PEAK, "traffic": None, "traffic_bytes_per_launch": None, "valu_frac": None,
+               "valu_busy_frac": None,
                "kernel": shard.model.kernel_name(), "kernel_ms": res["kernel_ms"], "kernel_fingerprint": fp,
                "algorithmic_bytes_per_column_step": algo_bytes}
         if args.arith != "p64":
@@ -363,6 +364,11 @@ def run_rank(args):
             valu_per_col = prof["SQ_INSTS_VALU"] / prof["SQ_WAVES"]       # one wave per column
             out["valu_instr_per_column_step"] = valu_per_col
             out["valu_frac"] = valu_per_col * ncol * VALU_CYCLES_PER_INSTR / (N_SIMD * CLOCK_HZ * kern_s)
+            if "SQ_ACTIVE_INST_VALU" in prof:
+                # the same with the measured issue time of the instructions (SQ_ACTIVE_INST_VALU counts 4-cycle slots;
+                # quarter-rate fp64 ops such as v_rcp_f64 take more than one), i.e. the fraction of time the VALUs are busy
+                busy = prof["SQ_ACTIVE_INST_VALU"] / prof["SQ_WAVES"] * 4.0
+                out["valu_busy_frac"] = busy * ncol / (N_SIMD * CLOCK_HZ * kern_s)
         out["note"] = ("fp64 transcendental-bound path (SURVEY 8d): the HBM fraction is reported as mandated; valu_frac = "
                        "VALU instructions per column-step (rocprofv3 --pmc profile of this code object) x 4 cycles / "
                        "(1024 SIMDs x 2.4 GHz x kernel time) is the side that binds; null = no profile of this build")

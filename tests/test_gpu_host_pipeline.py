@@ -148,3 +148,36 @@ def test_host_chunk_argument_checks(gpu_mixed):
     assert L.kidmp_set_host_chunk(gpu_mixed._h, -1) != 0
     assert L.kidmp_set_host_chunk(None, 16) != 0
     assert L.kidmp_host_register(None, 16) != 0
+
+
+def test_aerosol_aware_context_uploads_the_updraft(gpu_mixed_aero):
+    """is_aerosol_aware contexts read w (activ_ncloud, M:2797): the pipeline carries it as a 15th profile, chunk by chunk."""
+    ncol = 3000
+    st = cases.config3(ncol, seed=cases.SEED + 9)
+    rng = np.random.default_rng(11)
+    st["w"] = rng.uniform(-0.5, 8.0, size=(ncol, 1)) * np.ones_like(st["qv"])
+    st["nwfa"] = st["nwfa"] * rng.uniform(0.3, 30.0, size=(ncol, 1))
+    st = {k: np.ascontiguousarray(st[k]) for k in KEYS}
+    ref, ref_ppt, _, _ = _device_reference(gpu_mixed_aero, st, 10.0, False)
+    got = {k: thompson.host_pinned_copy(st[k]) for k in KEYS}
+    gpu_mixed_aero.set_host_chunk(640)                       # five chunks, the last one ragged
+    try:
+        ppt, _ = gpu_mixed_aero.batch_step_host(got, 10.0)
+    finally:
+        gpu_mixed_aero.set_host_chunk(0)
+    for k in STATE_NAMES:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(ppt, ref_ppt)
+    # and w matters: another updraft, another droplet number
+    other = {k: st[k].copy() for k in KEYS}
+    other["w"] = other["w"] + 2.0
+    gpu_mixed_aero.batch_step_host(other, 10.0)
+    assert not np.array_equal(other["nc"], got["nc"])
+    # a missing updraft is refused, not read from address 0
+    L = thompson.load_library()
+    dp = C.POINTER(C.c_double)
+    args = [got[k].ctypes.data_as(dp) for k in KEYS]
+    args[KEYS.index("w")] = None
+    rc = L.kidmp_batch_step_host(gpu_mixed_aero._h, C.c_int64(ncol), C.c_int32(120), C.c_double(10.0), *args,
+                                 ppt.ctypes.data_as(dp), None)
+    assert rc != 0 and b"updraft" in L.kidmp_last_error(gpu_mixed_aero._h)
