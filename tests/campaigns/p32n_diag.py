@@ -1,4 +1,6 @@
-import sys; sys.path[:0]=['/root/repo','/root/repo/tests']
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
 import numpy as np, cases, kat_cases as kc
 from kid_amd import ThompsonMP
 from oracle.oracle import Oracle

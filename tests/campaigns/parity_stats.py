@@ -11,7 +11,7 @@ One step from identical inputs, tests/parity.py's branch-aware comparison (NO le
                         of the port": if the oracle itself moves by as much when its input moves by an ulp, no
                         implementation can do better there.
 
-    python tools/parity_stats.py [--ncol 20000] > profiles/rNN_parity_stats.jsonl
+    python tests/campaigns/parity_stats.py [--ncol 20000] > profiles/rNN_parity_stats.jsonl
 """
 import argparse
 import json
@@ -20,7 +20,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cases  # noqa: E402
