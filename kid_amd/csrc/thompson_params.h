@@ -81,6 +81,10 @@ struct Consts {
     // [96..127] 10**-n for n = -16 .. 15: the decade finder's scale factors (exact powers of ten, or their
     //           correctly rounded reciprocals)
     double lds_tab[128];
+    // graupel intercept (M:1639-1647) of a level without graupel (rg <= 5.E-5) and without supercooled rain above k_0:
+    // a constant of the scheme, evaluated once per arithmetic variant ON THE DEVICE by the kernel's own function
+    // (upload_consts), so that it carries exactly the bits the per-level evaluation would produce
+    double n0g_empty;
 };
 
 // bins and axes needed only while building tables (device copies)
