@@ -90,6 +90,28 @@ def test_bench_launcher_spawns_ranks_and_reduces():
     np.testing.assert_allclose(d["precip_domain_sums"][0], 10 * 5 * 1e-3 * 10.0 * (1 + 2), rtol=1e-12)
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's own form at N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- the ranks exist already (WORLD_SIZE is set), so bench.py must
+    not spawn any and rank 0 must print the one line."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--backend", "gloo", "--rehearse-launcher", "--steps", "3", "--warmup", "1", "--ncol", "10"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1
+    np.testing.assert_allclose(d["precip_domain_sums"][0], 10 * 4 * 1e-3 * 10.0 * (1 + 2), rtol=1e-12)
+
+
 def test_bench_refuses_to_fake_a_gpu_run():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     import torch
