@@ -79,7 +79,14 @@ int kidmp_column_step(kidmp_ctx *ctx, int32_t nz, double dt,
 
 /* The `do i=1,nx` loop of the KiD adapter (W:54-246) as ONE batched call on
  * host arrays x[col*nz+k]; ppt is [ncol][4] (INOUT).  rates may be NULL, else
- * receives [ncol][KIDMP_NRATES][nz] (the save_dg values of M:2962-3124). */
+ * receives [ncol][KIDMP_NRATES][nz] (the save_dg values of M:2962-3124).
+ * Arrays KiD itself never fills may be left out (NULL) in all three host-array entries; they then neither cross
+ * PCIe nor come back:
+ *   nc, nwfa, nifa (all three or none)   contexts without is_aerosol_aware: the adapter passes them unset (W:36);
+ *                                        the non-aerosol defaults of M:958-964 are formed on the device
+ *   qi, qs, qg, ni (all four or none)    iiwarm contexts: a warm run keeps the frozen species at zero (W:46-52)
+ *   w                                    contexts without is_aerosol_aware (never read)
+ * A context that reads them (aerosol-aware / mixed-phase) refuses the call instead. */
 int kidmp_batch_step_host(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
                           double *qv, double *qc, double *qi, double *qr,
                           double *qs, double *qg, double *ni, double *nr,

@@ -115,16 +115,17 @@ int check_on_device(kidmp_ctx *c, const void *p, const char *what)
     return KIDMP_OK;
 }
 
-__global__ void k_default_aerosols(int64_t n, double Nt_c, const double *__restrict__ qv, const double *__restrict__ t,
-                                   const double *__restrict__ p, double *__restrict__ nc, double *__restrict__ nwfa,
-                                   double *__restrict__ nifa)
+// the non-aerosol defaults of M:958-964 in the state's own arithmetic (REAL expressions of the reference)
+template <class T>
+__global__ void k_default_aerosols(int64_t n, T Nt_c, const T *__restrict__ qv, const T *__restrict__ t,
+                                   const T *__restrict__ p, T *__restrict__ nc, T *__restrict__ nwfa, T *__restrict__ nifa)
 {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double rho = 0.622 * p[i] / (Rgas * t[i] * (qv[i] + 0.622));     // M:959
-    nc[i] = Nt_c / rho;                                                    // M:960
-    nwfa[i] = 11.1E6 / rho;                                                // M:961
-    nifa[i] = naIN1 * 0.01 / rho;                                          // M:962
+    const T rho = T(0.622) * p[i] / (T(Rgas) * t[i] * (qv[i] + T(0.622)));   // M:959
+    nc[i] = Nt_c / rho;                                                      // M:960
+    nwfa[i] = T(11.1E6) / rho;                                               // M:961
+    nifa[i] = T(naIN1) * T(0.01) / rho;                                      // M:962
 }
 
 // out4[s] = sum over columns of ppt[col][s]; one block, fixed order => reproducible
@@ -351,9 +352,27 @@ template <class T, class Launch>
 int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const *io, const T *const *in, T *ppt,
                   double *rates, int32_t *nstep, Launch launch)
 {
-    const void *ptrs[] = {io[0], io[1], io[2], io[3], io[4], io[5], io[6], io[7], io[8], io[9], io[10], io[11], in[0], in[1], ppt};
-    if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, 15)) return rc;
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    // Arrays the caller may leave out (NULL), as KiD itself does (W:36 passes nc1d, nwfa1d, nifa1d unset; a warm run
+    // never touches the frozen species, W:46-52): they then neither cross PCIe nor come back.
+    //   nc, nwfa, nifa (all three)   non-aerosol contexts: the defaults of M:958-964, formed on the device
+    //   qi, qs, qg, ni (all four)    iiwarm contexts: exactly zero (and they stay zero)
     const bool has_w = ctx->cfg.is_aerosol_aware != 0;
+    const int n_aer = (io[8] != nullptr) + (io[9] != nullptr) + (io[10] != nullptr);
+    const int n_frz = (io[2] != nullptr) + (io[4] != nullptr) + (io[5] != nullptr) + (io[6] != nullptr);
+    const bool skip_aer = n_aer == 0 && ncol > 0, skip_frz = n_frz == 0 && ncol > 0;
+    if (ncol > 0 && n_aer != 0 && n_aer != 3) return fail(ctx, KIDMP_EINVAL, "kidmp: nc, nwfa, nifa must be given or left out together");
+    if (ncol > 0 && n_frz != 0 && n_frz != 4) return fail(ctx, KIDMP_EINVAL, "kidmp: qi, qs, qg, ni must be given or left out together");
+    if (skip_aer && has_w) return fail(ctx, KIDMP_EINVAL, "kidmp: an aerosol-aware context needs nc, nwfa and nifa");
+    if (skip_frz && !ctx->cfg.iiwarm) return fail(ctx, KIDMP_EINVAL, "kidmp: a mixed-phase context needs qi, qs, qg and ni");
+    const void *ptrs[15];
+    int np = 0;
+    for (int v = 0; v < 12; ++v) {
+        const bool optional_out = (skip_aer && v >= 8 && v <= 10) || (skip_frz && (v == 2 || v == 4 || v == 5 || v == 6));
+        if (!optional_out) ptrs[np++] = io[v];
+    }
+    ptrs[np++] = in[0]; ptrs[np++] = in[1]; ptrs[np++] = ppt;
+    if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, np)) return rc;
     if (has_w && !in[2] && ncol > 0) return fail(ctx, KIDMP_EINVAL, "kidmp: an aerosol-aware context needs the updraft profile w");
     if (ncol == 0) return KIDMP_OK;
     GUARD(ctx);
@@ -393,17 +412,26 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
         if (!has_w || !in[2]) din[2] = nullptr;
         // upload (the set is free once the download of the chunk that used it last has finished)
         if (i >= nbuf) HIPTRY(ctx, hipStreamWaitEvent(ctx->s_h2d, ctx->ev_down[b], 0));
-        for (int v = 0; v < 12; ++v) HIPTRY(ctx, hipMemcpyAsync(dio[v], io[v] + off, cnt * sizeof(T), hipMemcpyHostToDevice, ctx->s_h2d));
+        for (int v = 0; v < 12; ++v)
+            if (io[v]) HIPTRY(ctx, hipMemcpyAsync(dio[v], io[v] + off, cnt * sizeof(T), hipMemcpyHostToDevice, ctx->s_h2d));
         for (int v = 0; v < (din[2] ? 3 : 2); ++v) HIPTRY(ctx, hipMemcpyAsync(dinw[v], in[v] + off, cnt * sizeof(T), hipMemcpyHostToDevice, ctx->s_h2d));
         HIPTRY(ctx, hipMemcpyAsync(dppt, ppt + 4 * c0, 4 * size_t(n) * sizeof(T), hipMemcpyHostToDevice, ctx->s_h2d));
         HIPTRY(ctx, hipEventRecord(ctx->ev_up[b], ctx->s_h2d));
         // step
         HIPTRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_up[b], 0));
+        if (skip_frz)
+            for (int v : {2, 4, 5, 6}) HIPTRY(ctx, hipMemsetAsync(dio[v], 0, cnt * sizeof(T), ctx->stream));
+        if (skip_aer) {
+            hipLaunchKernelGGL(k_default_aerosols<T>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, ctx->stream, int64_t(cnt),
+                               T(ctx->hc.Nt_c), dio[0], dio[11], din[0], dio[8], dio[9], dio[10]);
+            HIPTRY(ctx, hipGetLastError());
+        }
         if (int rc = launch(n, dio, din, dppt, drates, dnstep)) { (void)hipDeviceSynchronize(); return rc; }
         HIPTRY(ctx, hipEventRecord(ctx->ev_step[b], ctx->stream));
         // download
         HIPTRY(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->ev_step[b], 0));
-        for (int v = 0; v < 12; ++v) HIPTRY(ctx, hipMemcpyAsync(io[v] + off, dio[v], cnt * sizeof(T), hipMemcpyDeviceToHost, ctx->s_d2h));
+        for (int v = 0; v < 12; ++v)
+            if (io[v]) HIPTRY(ctx, hipMemcpyAsync(io[v] + off, dio[v], cnt * sizeof(T), hipMemcpyDeviceToHost, ctx->s_d2h));
         HIPTRY(ctx, hipMemcpyAsync(ppt + 4 * c0, dppt, 4 * size_t(n) * sizeof(T), hipMemcpyDeviceToHost, ctx->s_d2h));
         if (rates) HIPTRY(ctx, hipMemcpyAsync(rates + size_t(KIDMP_NRATES) * off, drates, size_t(KIDMP_NRATES) * cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->s_d2h));
         if (nstep) HIPTRY(ctx, hipMemcpyAsync(nstep + 4 * c0, dnstep, 4 * size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_d2h));
@@ -670,7 +698,7 @@ int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n, const double *qv, c
     if (int rc = check_on_device(ctx, qv, "qv")) return rc;
     if (int rc = check_on_device(ctx, nc, "nc")) return rc;
     const int T = 256;
-    hipLaunchKernelGGL(k_default_aerosols, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(k_default_aerosols<double>, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, (hipStream_t)stream, n,
                        ctx->hc.Nt_c, qv, t, p, nc, nwfa, nifa);
     HIPTRY(ctx, hipGetLastError());
     return KIDMP_OK;

@@ -84,6 +84,7 @@ module module_mp_thompson09n
        type(c_ptr), value :: ctx
        type(c_ptr) :: msg
      end function kidmp_last_error
+     ! arrays by address: the ones KiD never fills (nc, nwfa, nifa, w; the frozen species of a warm run) may be NULL
      integer(c_int) function kidmp_batch_step_host_diag(ctx, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, &
           nc, nwfa, nifa, t, p, w, dz, ppt, rates, nstep) bind(C, name='kidmp_batch_step_host_diag')
        import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
@@ -91,9 +92,7 @@ module module_mp_thompson09n
        integer(c_int64_t), value :: ncol
        integer(c_int32_t), value :: nz
        real(c_double), value :: dt
-       real(c_double), intent(inout) :: qv(*), qc(*), qi(*), qr(*), qs(*), qg(*), ni(*), nr(*), &
-            nc(*), nwfa(*), nifa(*), t(*), ppt(*)
-       real(c_double), intent(in) :: p(*), w(*), dz(*)
+       type(c_ptr), value :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt   ! real(c_double) [ncol][nz]; ppt [ncol][4]
        type(c_ptr), value :: rates, nstep            ! NULL, or [ncol][36][nz] doubles / [ncol][4] int32
      end function kidmp_batch_step_host_diag
      type(c_ptr) function kidmp_host_alloc(bytes) bind(C, name='kidmp_host_alloc')   ! page-locked host memory
@@ -111,9 +110,7 @@ module module_mp_thompson09n
        integer(c_int64_t), value :: ncol
        integer(c_int32_t), value :: nz, arith
        real(c_float), value :: dt
-       real(c_float), intent(inout) :: qv(*), qc(*), qi(*), qr(*), qs(*), qg(*), ni(*), nr(*), &
-            nc(*), nwfa(*), nifa(*), t(*), ppt(*)
-       real(c_float), intent(in) :: p(*), w(*), dz(*)
+       type(c_ptr), value :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt   ! real(c_float)
        type(c_ptr), value :: rates, nstep            ! NULL, or [ncol][36][nz] doubles / [ncol][4] int32
      end function kidmp32_batch_step_host
   end interface
@@ -205,21 +202,33 @@ contains
 
   ! ncol columns in one launch.  Arrays are (nz, ncol), k fastest -- KiD's own
   ! storage order -- and ppt is (4, ncol) = rain, snow, graupel, ice, accumulated.
+  ! What KiD never fills may be left out (keyword call): nc, nwfa, nifa and w without is_aerosol_aware (W:36 passes
+  ! them unset; the library forms the non-aerosol defaults of M:958-964 on the GPU), qi, qs, qg, ni in an iiwarm run
+  ! (they stay zero, W:46-52).  Absent arrays are neither staged nor sent across PCIe.
   subroutine mp_thompson_batch(ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt)
     integer, intent(in) :: ncol, nz
     real, intent(in) :: dt
-    real, dimension(nz,ncol), intent(inout) :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t
-    real, dimension(nz,ncol), intent(in) :: p, w, dz
+    real, dimension(nz,ncol), intent(inout) :: qv, qc, qr, nr, t
+    real, dimension(nz,ncol), intent(inout), optional :: qi, qs, qg, ni, nc, nwfa, nifa
+    real, dimension(nz,ncol), intent(in) :: p, dz
+    real, dimension(nz,ncol), intent(in), optional :: w
     real, dimension(4,ncol), intent(inout) :: ppt
     real(c_double), pointer :: s(:,:,:), f(:,:,:), pp(:,:), rates(:,:,:)
     real(c_float), pointer :: s4(:,:,:), f4(:,:,:), pp4(:,:)
     integer(c_int32_t), pointer :: nstep(:,:)
-    type(c_ptr) :: prates, pnstep
+    type(c_ptr) :: prates, pnstep, ps(12), pf(3)
     integer(c_size_t) :: nprof
     integer(c_int) :: rc
     integer(c_int32_t) :: arith
+    logical :: have_frz, have_aer
     integer :: i, k, r, r0
     if (.not. c_associated(ctx)) call thompson_init
+    have_frz = present(qi);  have_aer = present(nc)
+    if ((have_frz .neqv. present(qs)) .or. (have_frz .neqv. present(qg)) .or. (have_frz .neqv. present(ni)) .or. &
+        (have_aer .neqv. present(nwfa)) .or. (have_aer .neqv. present(nifa))) then
+       write(*,'(a)') ' module_mp_thompson09n: qi, qs, qg, ni (and nc, nwfa, nifa) must be passed or left out together'
+       stop 1
+    end if
     prates = c_null_ptr;  pnstep = c_null_ptr
     nprof = int(nz, c_size_t) * int(ncol, c_size_t)
     if (l_rate_diagnostics) then
@@ -229,6 +238,7 @@ contains
        call c_f_pointer(hbuf(5), nstep, [4, ncol])
        prates = hbuf(4);  pnstep = hbuf(5)
     end if
+    ps = c_null_ptr;  pf = c_null_ptr
     if (trim(kidmp_arith) /= 'p64') then
        ! ---- binary32 state straight to the GPU: the reference's own REAL / DOUBLE PRECISION split, or all binary32 ----
        if (kind(qv) /= c_float) then
@@ -239,34 +249,70 @@ contains
        if (trim(kidmp_arith) == 'f32') arith = 1_c_int32_t
        call staging(1, 4_c_size_t * 12 * nprof);  call staging(2, 4_c_size_t * 3 * nprof);  call staging(3, 16_c_size_t * ncol)
        call c_f_pointer(hbuf(1), s4, [nz, ncol, 12]);  call c_f_pointer(hbuf(2), f4, [nz, ncol, 3]);  call c_f_pointer(hbuf(3), pp4, [4, ncol])
-       s4(:,:,1) = qv;  s4(:,:,2) = qc;  s4(:,:,3) = qi;   s4(:,:,4) = qr
-       s4(:,:,5) = qs;  s4(:,:,6) = qg;  s4(:,:,7) = ni;   s4(:,:,8) = nr
-       s4(:,:,9) = nc;  s4(:,:,10) = nwfa; s4(:,:,11) = nifa; s4(:,:,12) = t
-       f4(:,:,1) = p;   f4(:,:,2) = w;   f4(:,:,3) = dz
+       s4(:,:,1) = qv;  s4(:,:,2) = qc;  s4(:,:,4) = qr;  s4(:,:,8) = nr;  s4(:,:,12) = t
+       if (have_frz) then
+          s4(:,:,3) = qi;  s4(:,:,5) = qs;  s4(:,:,6) = qg;  s4(:,:,7) = ni
+       end if
+       if (have_aer) then
+          s4(:,:,9) = nc;  s4(:,:,10) = nwfa;  s4(:,:,11) = nifa
+       end if
+       f4(:,:,1) = p;  f4(:,:,3) = dz
+       if (present(w)) f4(:,:,2) = w
        pp4 = ppt
+       do i = 1, 12
+          ps(i) = c_loc(s4(1,1,i))
+       end do
+       pf(1) = c_loc(f4(1,1,1));  pf(3) = c_loc(f4(1,1,3))
+       if (present(w)) pf(2) = c_loc(f4(1,1,2))
+       if (.not. have_frz) then
+          ps(3) = c_null_ptr;  ps(5) = c_null_ptr;  ps(6) = c_null_ptr;  ps(7) = c_null_ptr
+       end if
+       if (.not. have_aer) ps(9:11) = c_null_ptr
        rc = kidmp32_batch_step_host(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_float), &
-            s4(:,:,1), s4(:,:,2), s4(:,:,3), s4(:,:,4), s4(:,:,5), s4(:,:,6), s4(:,:,7), s4(:,:,8), &
-            s4(:,:,9), s4(:,:,10), s4(:,:,11), s4(:,:,12), f4(:,:,1), f4(:,:,2), f4(:,:,3), pp4, prates, pnstep, arith)
+            ps(1), ps(2), ps(3), ps(4), ps(5), ps(6), ps(7), ps(8), ps(9), ps(10), ps(11), ps(12), &
+            pf(1), pf(2), pf(3), c_loc(pp4), prates, pnstep, arith)
        call stop_on_error(rc, 'mp_thompson')
-       qv = s4(:,:,1);  qc = s4(:,:,2);  qi = s4(:,:,3);   qr = s4(:,:,4)
-       qs = s4(:,:,5);  qg = s4(:,:,6);  ni = s4(:,:,7);   nr = s4(:,:,8)
-       nc = s4(:,:,9);  nwfa = s4(:,:,10); nifa = s4(:,:,11); t = s4(:,:,12)
+       qv = s4(:,:,1);  qc = s4(:,:,2);  qr = s4(:,:,4);  nr = s4(:,:,8);  t = s4(:,:,12)
+       if (have_frz) then
+          qi = s4(:,:,3);  qs = s4(:,:,5);  qg = s4(:,:,6);  ni = s4(:,:,7)
+       end if
+       if (have_aer) then
+          nc = s4(:,:,9);  nwfa = s4(:,:,10);  nifa = s4(:,:,11)
+       end if
        ppt = pp4
     else
     call staging(1, 8_c_size_t * 12 * nprof);  call staging(2, 8_c_size_t * 3 * nprof);  call staging(3, 32_c_size_t * ncol)
     call c_f_pointer(hbuf(1), s, [nz, ncol, 12]);  call c_f_pointer(hbuf(2), f, [nz, ncol, 3]);  call c_f_pointer(hbuf(3), pp, [4, ncol])
-    s(:,:,1) = qv;  s(:,:,2) = qc;  s(:,:,3) = qi;   s(:,:,4) = qr
-    s(:,:,5) = qs;  s(:,:,6) = qg;  s(:,:,7) = ni;   s(:,:,8) = nr
-    s(:,:,9) = nc;  s(:,:,10) = nwfa; s(:,:,11) = nifa; s(:,:,12) = t
-    f(:,:,1) = p;   f(:,:,2) = w;   f(:,:,3) = dz
+    s(:,:,1) = qv;  s(:,:,2) = qc;  s(:,:,4) = qr;  s(:,:,8) = nr;  s(:,:,12) = t
+    if (have_frz) then
+       s(:,:,3) = qi;  s(:,:,5) = qs;  s(:,:,6) = qg;  s(:,:,7) = ni
+    end if
+    if (have_aer) then
+       s(:,:,9) = nc;  s(:,:,10) = nwfa;  s(:,:,11) = nifa
+    end if
+    f(:,:,1) = p;  f(:,:,3) = dz
+    if (present(w)) f(:,:,2) = w
     pp = ppt
+    do i = 1, 12
+       ps(i) = c_loc(s(1,1,i))
+    end do
+    pf(1) = c_loc(f(1,1,1));  pf(3) = c_loc(f(1,1,3))
+    if (present(w)) pf(2) = c_loc(f(1,1,2))
+    if (.not. have_frz) then
+       ps(3) = c_null_ptr;  ps(5) = c_null_ptr;  ps(6) = c_null_ptr;  ps(7) = c_null_ptr
+    end if
+    if (.not. have_aer) ps(9:11) = c_null_ptr
     rc = kidmp_batch_step_host_diag(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_double), &
-         s(:,:,1), s(:,:,2), s(:,:,3), s(:,:,4), s(:,:,5), s(:,:,6), s(:,:,7), s(:,:,8), &
-         s(:,:,9), s(:,:,10), s(:,:,11), s(:,:,12), f(:,:,1), f(:,:,2), f(:,:,3), pp, prates, pnstep)
+         ps(1), ps(2), ps(3), ps(4), ps(5), ps(6), ps(7), ps(8), ps(9), ps(10), ps(11), ps(12), &
+         pf(1), pf(2), pf(3), c_loc(pp), prates, pnstep)
     call stop_on_error(rc, 'mp_thompson')
-    qv = s(:,:,1);  qc = s(:,:,2);  qi = s(:,:,3);   qr = s(:,:,4)
-    qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7);   nr = s(:,:,8)
-    nc = s(:,:,9);  nwfa = s(:,:,10); nifa = s(:,:,11); t = s(:,:,12)
+    qv = s(:,:,1);  qc = s(:,:,2);  qr = s(:,:,4);  nr = s(:,:,8);  t = s(:,:,12)
+    if (have_frz) then
+       qi = s(:,:,3);  qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7)
+    end if
+    if (have_aer) then
+       nc = s(:,:,9);  nwfa = s(:,:,10);  nifa = s(:,:,11)
+    end if
     ppt = pp
     end if
     ! ---- the KiD block of M:2962-3124: per column, per level, 30 mixed-phase rates (.not. iiwarm) then 6 warm

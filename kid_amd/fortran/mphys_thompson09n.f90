@@ -72,16 +72,20 @@ contains
           end do
        end do
     end do
-    ! what the reference leaves unset: droplet / aerosol numbers from the non-aerosol defaults, no updraft
+    ! What the reference leaves unset (nc1d, nwfa1d, nifa1d, w1d; W:36): with is_aerosol_aware they are read, and get
+    ! the scheme's non-aerosol defaults (M:958-964) and no updraft here; without it they are left out of the call and
+    ! the library forms the same defaults on the GPU, so they never cross PCIe.
     wvel = 0.0
-    do i = 1, nx
-       do k = 1, nz
-          rho = 0.622*pres(k,i)/(287.04*st(k,i,S_T)*(st(k,i,S_QV)+0.622))
-          st(k,i,S_NC)   = set_Nc*1.e6/rho
-          st(k,i,S_NWFA) = 11.1E6/rho
-          st(k,i,S_NIFA) = 0.5E6*0.01/rho
+    if (is_aerosol_aware) then
+       do i = 1, nx
+          do k = 1, nz
+             rho = 0.622*pres(k,i)/(287.04*st(k,i,S_T)*(st(k,i,S_QV)+0.622))
+             st(k,i,S_NC)   = set_Nc*1.e6/rho
+             st(k,i,S_NWFA) = 11.1E6/rho
+             st(k,i,S_NIFA) = 0.5E6*0.01/rho
+          end do
        end do
-    end do
+    end if
 
     if (micro_unset) then                        ! W:100-103
        call thompson_init
@@ -90,9 +94,17 @@ contains
 
     ! ---- all nx columns in one call (replaces the loop around W:143-152) ----
     ppt = 0.0
-    call mp_thompson_batch(nx, nz, dt, st(:,:,S_QV), st(:,:,S_QC), st(:,:,S_QI), st(:,:,S_QR), st(:,:,S_QS), &
-         st(:,:,S_QG), st(:,:,S_NI), st(:,:,S_NR), st(:,:,S_NC), st(:,:,S_NWFA), st(:,:,S_NIFA), st(:,:,S_T), &
-         pres, wvel, dzc, ppt)
+    if (is_aerosol_aware) then
+       call mp_thompson_batch(nx, nz, dt, st(:,:,S_QV), st(:,:,S_QC), st(:,:,S_QI), st(:,:,S_QR), st(:,:,S_QS), &
+            st(:,:,S_QG), st(:,:,S_NI), st(:,:,S_NR), st(:,:,S_NC), st(:,:,S_NWFA), st(:,:,S_NIFA), st(:,:,S_T), &
+            pres, wvel, dzc, ppt)
+    else if (iiwarm) then                        ! a warm run: the frozen species stay zero (W:46-52) and stay at home
+       call mp_thompson_batch(nx, nz, dt, qv=st(:,:,S_QV), qc=st(:,:,S_QC), qr=st(:,:,S_QR), nr=st(:,:,S_NR), &
+            t=st(:,:,S_T), p=pres, dz=dzc, ppt=ppt)
+    else
+       call mp_thompson_batch(nx, nz, dt, qv=st(:,:,S_QV), qc=st(:,:,S_QC), qi=st(:,:,S_QI), qr=st(:,:,S_QR), &
+            qs=st(:,:,S_QS), qg=st(:,:,S_QG), ni=st(:,:,S_NI), nr=st(:,:,S_NR), t=st(:,:,S_T), p=pres, dz=dzc, ppt=ppt)
+    end if
 
     ! ---- back out the microphysics tendencies, W:198-245 ----
     do i = 1, nx

@@ -214,17 +214,23 @@ class ThompsonMP:
 
     # ---- batched host entry: numpy [ncol, nz] ----
     def batch_step_host(self, st, dt, ppt=None, want_rates=False):
+        """numpy float64 [ncol, nz] arrays, in place.  Keys KiD itself never fills may be missing (or None): nc, nwfa,
+        nifa and w for a context without aerosol_aware, qi, qs, qg, ni for an iiwarm context (include/kidmp.h)."""
         ncol, nz = st["qv"].shape
+        ptrs = []
         for k in STATE_NAMES + FORCING_NAMES:
-            a = st[k]
+            a = st.get(k)
+            if a is None:
+                ptrs.append(None)
+                continue
             if not (a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (ncol, nz)):
                 raise KidmpError("batch_step_host: %s must be contiguous float64 [ncol, nz]" % k)
+            ptrs.append(_np_ptr(a))
         if ppt is None:
             ppt = np.zeros((ncol, 4))
         rates = np.zeros((ncol, NRATES, nz)) if want_rates else None
         self._check(load_library().kidmp_batch_step_host(
-            self._h, ncol, nz, float(dt), *[_np_ptr(st[k]) for k in STATE_NAMES + FORCING_NAMES],
-            _np_ptr(ppt), _np_ptr(rates) if want_rates else None))
+            self._h, ncol, nz, float(dt), *ptrs, _np_ptr(ppt), _np_ptr(rates) if want_rates else None))
         return ppt, rates
 
     def _want(self, a, dtype, shape, what):

@@ -181,3 +181,51 @@ def test_aerosol_aware_context_uploads_the_updraft(gpu_mixed_aero):
     rc = L.kidmp_batch_step_host(gpu_mixed_aero._h, C.c_int64(ncol), C.c_int32(120), C.c_double(10.0), *args,
                                  ppt.ctypes.data_as(dp), None)
     assert rc != 0 and b"updraft" in L.kidmp_last_error(gpu_mixed_aero._h)
+
+
+def test_arrays_kid_never_fills_may_be_left_out(gpu_warm, gpu_mixed):
+    """nc, nwfa, nifa (W:36 passes them unset) and, in a warm run, the frozen species: left out of the host-array call they
+    neither cross PCIe nor come back, and the step is the one the full call makes with the defaults / zeros in place."""
+    ncol = 3000
+    st = _state("warm", ncol)
+    for k in ("qi", "qs", "qg", "ni"):
+        st[k][...] = 0.0
+    d = {k: torch.as_tensor(st[k]).cuda() for k in KEYS}
+    nc, nwfa, nifa = gpu_warm.default_aerosols(d["qv"], d["t"], d["p"])
+    full = {k: st[k].copy() for k in KEYS}
+    full["nc"], full["nwfa"], full["nifa"] = nc.cpu().numpy(), nwfa.cpu().numpy(), nifa.cpu().numpy()
+    ppt_full, _ = gpu_warm.batch_step_host(full, 10.0)
+    lean = {k: thompson.host_pinned_copy(st[k]) for k in ("qv", "qc", "qr", "nr", "t", "p", "dz")}
+    gpu_warm.set_host_chunk(1024)
+    try:
+        ppt_lean, _ = gpu_warm.batch_step_host(lean, 10.0)
+    finally:
+        gpu_warm.set_host_chunk(0)
+    for k in ("qv", "qc", "qr", "nr", "t"):
+        assert np.array_equal(lean[k], full[k]), k
+    assert np.array_equal(ppt_lean, ppt_full) and ppt_lean[:, 0].sum() > 0
+    # mixed-phase context: only the aerosol arrays may be missing
+    stm = _state("mixed", 1500)
+    dm = {k: torch.as_tensor(stm[k]).cuda() for k in KEYS}
+    nc, nwfa, nifa = gpu_mixed.default_aerosols(dm["qv"], dm["t"], dm["p"])
+    fullm = {k: stm[k].copy() for k in KEYS}
+    fullm["nc"], fullm["nwfa"], fullm["nifa"] = nc.cpu().numpy(), nwfa.cpu().numpy(), nifa.cpu().numpy()
+    pf, _ = gpu_mixed.batch_step_host(fullm, 10.0)
+    leanm = {k: stm[k].copy() for k in KEYS if k not in ("nc", "nwfa", "nifa", "w")}
+    pl, _ = gpu_mixed.batch_step_host(leanm, 10.0)
+    for k in leanm:
+        assert np.array_equal(leanm[k], fullm[k]), k
+    assert np.array_equal(pl, pf)
+    # what a context reads cannot be left out, and the groups go together
+    from kid_amd import KidmpError
+    with pytest.raises(KidmpError, match="mixed-phase context needs"):
+        gpu_mixed.batch_step_host({k: stm[k].copy() for k in ("qv", "qc", "qr", "nr", "t", "p", "dz")}, 10.0)
+    with pytest.raises(KidmpError, match="together"):
+        gpu_mixed.batch_step_host({k: stm[k].copy() for k in KEYS if k != "nwfa"}, 10.0)
+
+
+def test_aerosol_aware_context_refuses_missing_aerosols(gpu_mixed_aero):
+    from kid_amd import KidmpError
+    st = _state("mixed", 64)
+    with pytest.raises(KidmpError, match="aerosol-aware context needs"):
+        gpu_mixed_aero.batch_step_host({k: st[k].copy() for k in KEYS if k not in ("nc", "nwfa", "nifa")}, 10.0)
