@@ -40,7 +40,7 @@ module module_mp_thompson09n
   implicit none
   private
 
-  public :: thompson_init, mp_thompson, mp_thompson_batch, thompson_finalize
+  public :: thompson_init, mp_thompson, mp_thompson_batch, mp_thompson_staging, thompson_finalize
   logical, public :: is_aerosol_aware = .false.          ! M:28 (read at thompson_init)
   logical, public :: l_rate_diagnostics = .true.         ! replay the save_dg calls of M:2962-3124
   integer, public :: kidmp_device = 0                    ! HIP device ordinal of this process (one process per GPU)
@@ -200,6 +200,26 @@ contains
     if (.false.) print *, ii, jj          ! ii, jj are debug-only in the reference (M:1269-1274)
   end subroutine mp_thompson
 
+  ! The page-locked staging arrays themselves, for a caller whose default REAL is the storage type of kidmp_arith
+  ! (8-byte REAL with 'p64', 4-byte REAL with 'p32n' / 'f32'): st(nz,ncol,12) in the argument order of mp_thompson
+  ! (qv qc qi qr qs qg ni nr nc nwfa nifa t), fo(nz,ncol,3) = p, w, dz, pp(4,ncol).  Filled in place and passed to
+  ! mp_thompson_batch -- ALL of them, slot by slot -- they are not copied again, in or out.  ok = .false. (and null
+  ! pointers) when the kinds differ: the caller then brings its own arrays and mp_thompson_batch converts.
+  subroutine mp_thompson_staging(ncol, nz, st, fo, pp, ok)
+    integer, intent(in) :: ncol, nz
+    real, pointer, intent(out) :: st(:,:,:), fo(:,:,:), pp(:,:)
+    logical, intent(out) :: ok
+    integer(c_size_t) :: nprof, esize
+    nullify(st, fo, pp)
+    ok = (kind(1.0) == c_double .and. trim(kidmp_arith) == 'p64') .or. &
+         (kind(1.0) == c_float .and. trim(kidmp_arith) /= 'p64')
+    if (.not. ok) return
+    nprof = int(nz, c_size_t) * int(ncol, c_size_t)
+    esize = int(storage_size(1.0) / 8, c_size_t)
+    call staging(1, esize * 12 * nprof);  call staging(2, esize * 3 * nprof);  call staging(3, esize * 4 * ncol)
+    call c_f_pointer(hbuf(1), st, [nz, ncol, 12]);  call c_f_pointer(hbuf(2), fo, [nz, ncol, 3]);  call c_f_pointer(hbuf(3), pp, [4, ncol])
+  end subroutine mp_thompson_staging
+
   ! ncol columns in one launch.  Arrays are (nz, ncol), k fastest -- KiD's own
   ! storage order -- and ppt is (4, ncol) = rain, snow, graupel, ice, accumulated.
   ! What KiD never fills may be left out (keyword call): nc, nwfa, nifa and w without is_aerosol_aware (W:36 passes
@@ -208,11 +228,11 @@ contains
   subroutine mp_thompson_batch(ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt)
     integer, intent(in) :: ncol, nz
     real, intent(in) :: dt
-    real, dimension(nz,ncol), intent(inout) :: qv, qc, qr, nr, t
-    real, dimension(nz,ncol), intent(inout), optional :: qi, qs, qg, ni, nc, nwfa, nifa
-    real, dimension(nz,ncol), intent(in) :: p, dz
-    real, dimension(nz,ncol), intent(in), optional :: w
-    real, dimension(4,ncol), intent(inout) :: ppt
+    real, dimension(nz,ncol), intent(inout), target :: qv, qc, qr, nr, t
+    real, dimension(nz,ncol), intent(inout), optional, target :: qi, qs, qg, ni, nc, nwfa, nifa
+    real, dimension(nz,ncol), intent(in), target :: p, dz
+    real, dimension(nz,ncol), intent(in), optional, target :: w
+    real, dimension(4,ncol), intent(inout), target :: ppt
     real(c_double), pointer :: s(:,:,:), f(:,:,:), pp(:,:), rates(:,:,:)
     real(c_float), pointer :: s4(:,:,:), f4(:,:,:), pp4(:,:)
     integer(c_int32_t), pointer :: nstep(:,:)
@@ -220,7 +240,7 @@ contains
     integer(c_size_t) :: nprof
     integer(c_int) :: rc
     integer(c_int32_t) :: arith
-    logical :: have_frz, have_aer
+    logical :: have_frz, have_aer, inplace
     integer :: i, k, r, r0
     if (.not. c_associated(ctx)) call thompson_init
     have_frz = present(qi);  have_aer = present(nc)
@@ -249,6 +269,17 @@ contains
        if (trim(kidmp_arith) == 'f32') arith = 1_c_int32_t
        call staging(1, 4_c_size_t * 12 * nprof);  call staging(2, 4_c_size_t * 3 * nprof);  call staging(3, 16_c_size_t * ncol)
        call c_f_pointer(hbuf(1), s4, [nz, ncol, 12]);  call c_f_pointer(hbuf(2), f4, [nz, ncol, 3]);  call c_f_pointer(hbuf(3), pp4, [4, ncol])
+       ! (an argument that IS its staging slot -- mp_thompson_staging -- needs no copy, in or out)
+       inplace = c_associated(c_loc(qv), c_loc(s4(1,1,1))) .and. c_associated(c_loc(qc), c_loc(s4(1,1,2))) .and. &
+            c_associated(c_loc(qr), c_loc(s4(1,1,4))) .and. c_associated(c_loc(nr), c_loc(s4(1,1,8))) .and. &
+            c_associated(c_loc(t), c_loc(s4(1,1,12))) .and. c_associated(c_loc(p), c_loc(f4(1,1,1))) .and. &
+            c_associated(c_loc(dz), c_loc(f4(1,1,3))) .and. c_associated(c_loc(ppt), c_loc(pp4(1,1)))
+       if (inplace .and. have_frz) inplace = c_associated(c_loc(qi), c_loc(s4(1,1,3))) .and. c_associated(c_loc(qs), c_loc(s4(1,1,5))) &
+            .and. c_associated(c_loc(qg), c_loc(s4(1,1,6))) .and. c_associated(c_loc(ni), c_loc(s4(1,1,7)))
+       if (inplace .and. have_aer) inplace = c_associated(c_loc(nc), c_loc(s4(1,1,9))) .and. c_associated(c_loc(nwfa), c_loc(s4(1,1,10))) &
+            .and. c_associated(c_loc(nifa), c_loc(s4(1,1,11)))
+       if (inplace .and. present(w)) inplace = c_associated(c_loc(w), c_loc(f4(1,1,2)))
+       if (.not. inplace) then
        s4(:,:,1) = qv;  s4(:,:,2) = qc;  s4(:,:,4) = qr;  s4(:,:,8) = nr;  s4(:,:,12) = t
        if (have_frz) then
           s4(:,:,3) = qi;  s4(:,:,5) = qs;  s4(:,:,6) = qg;  s4(:,:,7) = ni
@@ -259,6 +290,7 @@ contains
        f4(:,:,1) = p;  f4(:,:,3) = dz
        if (present(w)) f4(:,:,2) = w
        pp4 = ppt
+       end if
        do i = 1, 12
           ps(i) = c_loc(s4(1,1,i))
        end do
@@ -272,6 +304,7 @@ contains
             ps(1), ps(2), ps(3), ps(4), ps(5), ps(6), ps(7), ps(8), ps(9), ps(10), ps(11), ps(12), &
             pf(1), pf(2), pf(3), c_loc(pp4), prates, pnstep, arith)
        call stop_on_error(rc, 'mp_thompson')
+       if (.not. inplace) then
        qv = s4(:,:,1);  qc = s4(:,:,2);  qr = s4(:,:,4);  nr = s4(:,:,8);  t = s4(:,:,12)
        if (have_frz) then
           qi = s4(:,:,3);  qs = s4(:,:,5);  qg = s4(:,:,6);  ni = s4(:,:,7)
@@ -280,9 +313,20 @@ contains
           nc = s4(:,:,9);  nwfa = s4(:,:,10);  nifa = s4(:,:,11)
        end if
        ppt = pp4
+       end if
     else
     call staging(1, 8_c_size_t * 12 * nprof);  call staging(2, 8_c_size_t * 3 * nprof);  call staging(3, 32_c_size_t * ncol)
     call c_f_pointer(hbuf(1), s, [nz, ncol, 12]);  call c_f_pointer(hbuf(2), f, [nz, ncol, 3]);  call c_f_pointer(hbuf(3), pp, [4, ncol])
+    inplace = c_associated(c_loc(qv), c_loc(s(1,1,1))) .and. c_associated(c_loc(qc), c_loc(s(1,1,2))) .and. &
+         c_associated(c_loc(qr), c_loc(s(1,1,4))) .and. c_associated(c_loc(nr), c_loc(s(1,1,8))) .and. &
+         c_associated(c_loc(t), c_loc(s(1,1,12))) .and. c_associated(c_loc(p), c_loc(f(1,1,1))) .and. &
+         c_associated(c_loc(dz), c_loc(f(1,1,3))) .and. c_associated(c_loc(ppt), c_loc(pp(1,1)))
+    if (inplace .and. have_frz) inplace = c_associated(c_loc(qi), c_loc(s(1,1,3))) .and. c_associated(c_loc(qs), c_loc(s(1,1,5))) &
+         .and. c_associated(c_loc(qg), c_loc(s(1,1,6))) .and. c_associated(c_loc(ni), c_loc(s(1,1,7)))
+    if (inplace .and. have_aer) inplace = c_associated(c_loc(nc), c_loc(s(1,1,9))) .and. c_associated(c_loc(nwfa), c_loc(s(1,1,10))) &
+         .and. c_associated(c_loc(nifa), c_loc(s(1,1,11)))
+    if (inplace .and. present(w)) inplace = c_associated(c_loc(w), c_loc(f(1,1,2)))
+    if (.not. inplace) then
     s(:,:,1) = qv;  s(:,:,2) = qc;  s(:,:,4) = qr;  s(:,:,8) = nr;  s(:,:,12) = t
     if (have_frz) then
        s(:,:,3) = qi;  s(:,:,5) = qs;  s(:,:,6) = qg;  s(:,:,7) = ni
@@ -293,6 +337,7 @@ contains
     f(:,:,1) = p;  f(:,:,3) = dz
     if (present(w)) f(:,:,2) = w
     pp = ppt
+    end if
     do i = 1, 12
        ps(i) = c_loc(s(1,1,i))
     end do
@@ -306,6 +351,7 @@ contains
          ps(1), ps(2), ps(3), ps(4), ps(5), ps(6), ps(7), ps(8), ps(9), ps(10), ps(11), ps(12), &
          pf(1), pf(2), pf(3), c_loc(pp), prates, pnstep)
     call stop_on_error(rc, 'mp_thompson')
+    if (.not. inplace) then
     qv = s(:,:,1);  qc = s(:,:,2);  qr = s(:,:,4);  nr = s(:,:,8);  t = s(:,:,12)
     if (have_frz) then
        qi = s(:,:,3);  qs = s(:,:,5);  qg = s(:,:,6);  ni = s(:,:,7)
@@ -314,6 +360,7 @@ contains
        nc = s(:,:,9);  nwfa = s(:,:,10);  nifa = s(:,:,11)
     end if
     ppt = pp
+    end if
     end if
     ! ---- the KiD block of M:2962-3124: per column, per level, 30 mixed-phase rates (.not. iiwarm) then 6 warm
     !      ones; save_dg(k, value, ...) when nx == 1, save_dg(k, ii, value, ...) otherwise; a column that left

@@ -50,15 +50,38 @@ contains
 
   Subroutine mphys_thompson09_interfacen
 
-    real :: st(nz,nx,NSLOT), pres(nz,nx), wvel(nz,nx), dzc(nz,nx), ppt(4,nx), total(nx), rho
+    ! Work arrays: the library's page-locked staging arrays themselves where KiD's REAL is what the selected arithmetic
+    ! stores (mp_thompson_staging; no copy between here and PCIe), else heap arrays kept between calls (as automatic
+    ! arrays they overflow the stack from nx ~ 500 on).  pres, wvel, dzc are fo(:,:,1:3).
+    real, pointer :: st(:,:,:), fo(:,:,:), ppt(:,:)
+    real, allocatable, target, save :: st_own(:,:,:), fo_own(:,:,:), ppt_own(:,:)
+    real, allocatable, save :: total(:)
+    real :: rho
+    logical :: staged
     integer :: i, k, m, s
 
+    if (micro_unset) then                        ! W:100-103 (ahead of the gather: the staging arrays belong to the library)
+       call thompson_init
+       micro_unset = .False.
+    end if
+    call mp_thompson_staging(nx, nz, st, fo, ppt, staged)
+    if (.not. staged) then
+       if (allocated(st_own)) then
+          if (size(st_own,1) /= nz .or. size(st_own,2) /= nx) deallocate(st_own, fo_own, ppt_own)
+       end if
+       if (.not. allocated(st_own)) allocate(st_own(nz,nx,NSLOT), fo_own(nz,nx,3), ppt_own(4,nx))
+       st => st_own;  fo => fo_own;  ppt => ppt_own
+    end if
+    if (allocated(total)) then
+       if (size(total) /= nx) deallocate(total)
+    end if
+    if (.not. allocated(total)) allocate(total(nx))
+
     ! ---- gather: state + (advective + divergence forcing)*dt, W:59-97 ----
-    st = 0.0                                     ! frozen species stay zero in warm runs (W:46-52, W:78)
     do i = 1, nx
        st(:,i,S_T)  = (theta(:,i) + (dtheta_adv(:,i) + dtheta_div(:,i))*dt)*exner(:,i)
-       pres(:,i)    = p0*exner(:,i)**(1./r_on_cp)
-       dzc(:,i)     = dz(:)
+       fo(:,i,1)    = p0*exner(:,i)**(1./r_on_cp)
+       fo(:,i,3)    = dz(:)
        st(:,i,S_QV) = qv(:,i) + (dqv_adv(:,i) + dqv_div(:,i))*dt
     end do
     do m = 1, NHYD
@@ -75,11 +98,11 @@ contains
     ! What the reference leaves unset (nc1d, nwfa1d, nifa1d, w1d; W:36): with is_aerosol_aware they are read, and get
     ! the scheme's non-aerosol defaults (M:958-964) and no updraft here; without it they are left out of the call and
     ! the library forms the same defaults on the GPU, so they never cross PCIe.
-    wvel = 0.0
     if (is_aerosol_aware) then
+       fo(:,:,2) = 0.0
        do i = 1, nx
           do k = 1, nz
-             rho = 0.622*pres(k,i)/(287.04*st(k,i,S_T)*(st(k,i,S_QV)+0.622))
+             rho = 0.622*fo(k,i,1)/(287.04*st(k,i,S_T)*(st(k,i,S_QV)+0.622))
              st(k,i,S_NC)   = set_Nc*1.e6/rho
              st(k,i,S_NWFA) = 11.1E6/rho
              st(k,i,S_NIFA) = 0.5E6*0.01/rho
@@ -87,23 +110,18 @@ contains
        end do
     end if
 
-    if (micro_unset) then                        ! W:100-103
-       call thompson_init
-       micro_unset = .False.
-    end if
-
     ! ---- all nx columns in one call (replaces the loop around W:143-152) ----
     ppt = 0.0
     if (is_aerosol_aware) then
        call mp_thompson_batch(nx, nz, dt, st(:,:,S_QV), st(:,:,S_QC), st(:,:,S_QI), st(:,:,S_QR), st(:,:,S_QS), &
             st(:,:,S_QG), st(:,:,S_NI), st(:,:,S_NR), st(:,:,S_NC), st(:,:,S_NWFA), st(:,:,S_NIFA), st(:,:,S_T), &
-            pres, wvel, dzc, ppt)
+            fo(:,:,1), fo(:,:,2), fo(:,:,3), ppt)
     else if (iiwarm) then                        ! a warm run: the frozen species stay zero (W:46-52) and stay at home
        call mp_thompson_batch(nx, nz, dt, qv=st(:,:,S_QV), qc=st(:,:,S_QC), qr=st(:,:,S_QR), nr=st(:,:,S_NR), &
-            t=st(:,:,S_T), p=pres, dz=dzc, ppt=ppt)
+            t=st(:,:,S_T), p=fo(:,:,1), dz=fo(:,:,3), ppt=ppt)
     else
        call mp_thompson_batch(nx, nz, dt, qv=st(:,:,S_QV), qc=st(:,:,S_QC), qi=st(:,:,S_QI), qr=st(:,:,S_QR), &
-            qs=st(:,:,S_QS), qg=st(:,:,S_QG), ni=st(:,:,S_NI), nr=st(:,:,S_NR), t=st(:,:,S_T), p=pres, dz=dzc, ppt=ppt)
+            qs=st(:,:,S_QS), qg=st(:,:,S_QG), ni=st(:,:,S_NI), nr=st(:,:,S_NR), t=st(:,:,S_T), p=fo(:,:,1), dz=fo(:,:,3), ppt=ppt)
     end if
 
     ! ---- back out the microphysics tendencies, W:198-245 ----

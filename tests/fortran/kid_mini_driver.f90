@@ -9,6 +9,7 @@
 !                dry   = the warm case without hydrometeors at 30 % of its vapour: mp_thompson returns at no_micro
 !     arith      p64 (default) | p32n | f32: module_mp_thompson09n's kidmp_arith (the last two need 4-byte default REAL)
 !     dump_step  write every save_dg call made during that step to dg_dump.txt (the recording `diagnostics` stub)
+!     norates    (6th argument) module_mp_thompson09n's l_rate_diagnostics = .false.
 ! Prints the end-state sums of column 1 and of column nx.
 program kid_mini_driver
   use parameters, only: nz, nx, dt
@@ -16,7 +17,7 @@ program kid_mini_driver
   use namelists, only: iiwarm, set_Nc
   use diagnostics, only: recording, nlog, dump_log
   use mphys_thompson09n, only: mphys_thompson09_interfacen
-  use module_mp_thompson09n, only: thompson_finalize, kidmp_arith
+  use module_mp_thompson09n, only: thompson_finalize, kidmp_arith, l_rate_diagnostics
   implicit none
   integer :: k, i, n, j, nsteps, dump_step
   real :: z, p, t, es, qsat
@@ -34,6 +35,10 @@ program kid_mini_driver
      call get_command_argument(4, arg); read(arg,*) dump_step
   end if
   if (command_argument_count() >= 5) call get_command_argument(5, kidmp_arith)   ! p64 (default) | p32n | f32
+  if (command_argument_count() >= 6) then
+     call get_command_argument(6, arg)
+     if (trim(arg) == 'norates') l_rate_diagnostics = .false.      ! timing runs: no replay of the 36 rate diagnostics
+  end if
   iiwarm = trim(which) /= 'mixed'; set_Nc = 100.0
   call alloc_columns(nz, nx)
   do i = 1, nx

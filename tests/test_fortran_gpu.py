@@ -50,6 +50,14 @@ def test_batched_adapter_columns_are_independent():
     assert np.array_equal(v["KATB"], v["KATBN"])        # replicated columns stay bit-identical
 
 
+def test_large_batches_through_the_fortran_drop_in():
+    """nx = 3000 columns (a 43 MB state: the adapter's work arrays must not live on the stack, the host-array call
+    runs as several pipeline chunks) end where nx = 5 ends, column for column."""
+    small, big = _run(5, 6), _run(3000, 6)
+    assert np.array_equal(big["KATB"], big["KATBN"])
+    assert np.array_equal(big["KATB"], small["KATB"])
+
+
 def test_default_real4_kid_build_runs_through_the_same_shim():
     """KiD's native build has 4-byte default REAL (the reference's "P32n" arithmetic keeps its state in fp32).
     The shim converts at the boundary, so the same modules serve that build; the end state then differs from the
