@@ -348,6 +348,19 @@ int64_t pick_host_chunk(const kidmp_ctx *ctx, int64_t ncol)
     return ch > 8192 ? 8192 : ch;                             // ... of at most 8 192 columns (7.9 MB per profile slice; measured optimum)
 }
 
+// Leaving host_pipeline with an error must not leave DMA in flight towards the caller's arrays.
+struct PipelineDrain {
+    kidmp_ctx *c;
+    bool armed = true;
+    ~PipelineDrain()
+    {
+        if (!armed) return;
+        (void)hipStreamSynchronize(c->s_h2d);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->s_d2h);
+    }
+};
+
 template <class T, class Launch>
 int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const *io, const T *const *in, T *ppt,
                   double *rates, int32_t *nstep, Launch launch)
@@ -396,6 +409,7 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
         ctx->stage_bytes = need;
     }
     char *const base = reinterpret_cast<char *>(ctx->d_stage);
+    PipelineDrain drain{ctx};
     for (int64_t i = 0; i < nchunk; ++i) {
         const int b = int(i % nbuf);
         const int64_t c0 = i * CH, n = (c0 + CH <= ncol ? CH : ncol - c0);
@@ -426,7 +440,7 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
                                T(ctx->hc.Nt_c), dio[0], dio[11], din[0], dio[8], dio[9], dio[10]);
             HIPTRY(ctx, hipGetLastError());
         }
-        if (int rc = launch(n, dio, din, dppt, drates, dnstep)) { (void)hipDeviceSynchronize(); return rc; }
+        if (int rc = launch(n, dio, din, dppt, drates, dnstep)) return rc;
         HIPTRY(ctx, hipEventRecord(ctx->ev_step[b], ctx->stream));
         // download
         HIPTRY(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->ev_step[b], 0));
@@ -437,7 +451,8 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
         if (nstep) HIPTRY(ctx, hipMemcpyAsync(nstep + 4 * c0, dnstep, 4 * size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->s_d2h));
         HIPTRY(ctx, hipEventRecord(ctx->ev_down[b], ctx->s_d2h));
     }
-    HIPTRY(ctx, hipStreamSynchronize(ctx->s_d2h));
+    HIPTRY(ctx, hipStreamSynchronize(ctx->s_d2h));           // everything else precedes it through the events
+    drain.armed = false;
     return KIDMP_OK;
 }
 
