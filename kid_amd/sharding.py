@@ -72,18 +72,22 @@ class ShardedColumns:
         import torch
         torch.cuda.synchronize(self.device)
 
-    def diagnostics(self, group=None, cpu_collective=False):
+    def diagnostics(self, group=None, cpu_collective=False, want_sanity=True):
         """Domain diagnostics over ALL ranks: dict(precip=[4] sums, sanity=[15] (7 maxima, 8 negative counts),
         rates=[36, nz] sums or None).  One RCCL all-gather of the per-rank vectors, reduced locally (SUM, and MAX for
-        the maxima); cpu_collective=True moves them to the host first (gloo rehearsals)."""
+        the maxima); cpu_collective=True moves them to the host first (gloo rehearsals).  want_sanity=False leaves the
+        max-q / negative-value scan out (the optional debugging aid of SURVEY 8e; it reads eight state arrays) and
+        returns zeros in its place: what remains is the reference adapter's own exchange, the precipitation means of
+        W:248-303."""
         import torch
         import torch.distributed as dist
         if self.arith == "p64":
             precip = self.model.reduce_ppt(self.ppt)
-            sanity = self.model.sanity(self.st)
+            sanity = self.model.sanity(self.st) if want_sanity else torch.zeros(15, dtype=torch.float64, device=precip.device)
         else:                                                  # the diagnostics kernels are binary64: convert the shard's view
             precip = self.model.reduce_ppt(self.ppt.double())
-            sanity = self.model.sanity({k: self.st[k].double() for k in self.model.SANITY_NEG})
+            sanity = (self.model.sanity({k: self.st[k].double() for k in self.model.SANITY_NEG}) if want_sanity
+                      else torch.zeros(15, dtype=torch.float64, device=precip.device))
         rates = self.model.reduce_rates(self.rates) if self.rates is not None else None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             # ONE collective: every rank contributes its [4 + 15 (+ 36 nz)] vector, the sums and maxima are then formed
