@@ -36,6 +36,19 @@ def test_no_signature_uses_torch_or_cxx_types():
     assert "torch" not in code and "std::" not in code and "hipStream_t" not in code and "#include <hip" not in code
 
 
+def test_header_compiles_as_strict_c99_and_cxx(tmp_path):
+    """include/kidmp.h is the boundary a C, C++ or Fortran (ISO_C_BINDING) host binds: it must stand alone."""
+    import subprocess
+    src = tmp_path / "use_kidmp.c"
+    src.write_text('#include "kidmp.h"\n'
+                   'int use(void) { kidmp_cfg c; c.iiwarm = 1; c.is_aerosol_aware = 0; return (int)sizeof(c) + KIDMP_NRATES + KIDMP_ARITH_F32; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-pedantic"], ["g++", "-std=c++11", "-pedantic", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "o.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
 def test_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
