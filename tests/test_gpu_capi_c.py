@@ -34,7 +34,7 @@ def test_c_program_equals_python_wrapper(tmp_path, gpu_warm):
     raw_out = np.fromfile(str(tmp_path / "capi_out.bin"), dtype=np.float64)
     assert raw_in.size == 7 * n and raw_out.size == 5 * n + 4 * ncol
     names_in, names_out = ("qv", "qc", "qr", "nr", "t", "p", "dz"), ("qv", "qc", "qr", "nr", "t")
-    st = {k: np.ascontiguousarray(raw_in[i * n:(i + 1) * n].reshape(ncol, nz)) for i, k in enumerate(names_in)}
+    st = {k: raw_in[i * n:(i + 1) * n].reshape(ncol, nz).copy() for i, k in enumerate(names_in)}
     assert st["qc"].max() == 8.0e-4 and st["dz"].min() == 25.0 and st["qr"][-1].max() > st["qr"][0].max()
     ppt = np.zeros((ncol, 4))
     for _ in range(nsteps):
