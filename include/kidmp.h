@@ -157,13 +157,11 @@ int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz);
  * three-stage pipeline over column chunks -- upload of chunk i+1, step of chunk i, download of chunk i-1 on three
  * streams -- which only overlaps if the DMA engines can reach the host arrays, i.e. if they are page-locked.
  * kidmp_host_alloc returns page-locked memory (NULL on failure, message in kidmp_last_error(NULL)); free it with
- * kidmp_host_free.  kidmp_host_register page-locks an existing allocation in place (undo with
- * kidmp_host_unregister BEFORE freeing it).  Pageable arrays are accepted too: results are the same, the copies
- * are then staged by the HIP runtime and do not overlap.  None of these four needs a context. */
+ * kidmp_host_free (memory the caller page-locked itself -- hipHostMalloc, hipHostRegister -- serves as well).  Pageable
+ * arrays are accepted too: results are the same, the copies are then staged by the HIP runtime and do not overlap.
+ * Neither function needs a context. */
 void *kidmp_host_alloc(size_t bytes);
 void kidmp_host_free(void *p);
-int kidmp_host_register(void *p, size_t bytes);
-int kidmp_host_unregister(void *p);
 /* Columns per pipeline chunk of this context's host-array entries; 0 (default) = a quarter of the batch, rounded up
  * to 256, at most 8 192 (one chunk for batches of <= 2048 columns). */
 int kidmp_set_host_chunk(kidmp_ctx *ctx, int64_t ncol_per_chunk);

@@ -335,7 +335,7 @@ int check_step_args(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, const v
 // The batch is cut into chunks of CH columns; chunk i is uploaded on the context's H2D stream, stepped on its compute
 // stream and downloaded on its D2H stream, through a ring of HOST_NBUF staging sets in HBM, so the two DMA directions
 // (PCIe is full duplex) and the kernel work on three different chunks at once.  Host arrays that are page-locked
-// (kidmp_host_alloc, kidmp_host_register, or the caller's own hipHostMalloc / hipHostRegister) are moved by the DMA
+// (kidmp_host_alloc, or the caller's own hipHostMalloc / hipHostRegister) are moved by the DMA
 // engines asynchronously; pageable arrays still work, but the runtime stages them through its own bounce buffer and
 // the calling thread waits for each copy.  Per column-step the boundary moves 14 (15 with w) profiles in and 12 out
 // (+36 for the rate diagnostics): about 25 KB in binary64.
@@ -596,19 +596,6 @@ void *kidmp_host_alloc(size_t bytes)
     return p;
 }
 void kidmp_host_free(void *p) { if (p) (void)hipHostFree(p); }
-int kidmp_host_register(void *p, size_t bytes)
-{
-    if (!p || !bytes) return fail(nullptr, KIDMP_EINVAL, "kidmp_host_register: null or empty range");
-    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
-    if (e != hipSuccess) { (void)hipGetLastError(); return hipfail(nullptr, e, "hipHostRegister"); }
-    return KIDMP_OK;
-}
-int kidmp_host_unregister(void *p)
-{
-    const hipError_t e = hipHostUnregister(p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return hipfail(nullptr, e, "hipHostUnregister"); }
-    return KIDMP_OK;
-}
 int kidmp_set_host_chunk(kidmp_ctx *ctx, int64_t ncol_per_chunk)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");

@@ -114,10 +114,6 @@ def load_library(path=None):
     L.kidmp_host_alloc.argtypes = [C.c_size_t]
     L.kidmp_host_free.restype = None
     L.kidmp_host_free.argtypes = [_vp]
-    L.kidmp_host_register.restype = C.c_int
-    L.kidmp_host_register.argtypes = [_vp, C.c_size_t]
-    L.kidmp_host_unregister.restype = C.c_int
-    L.kidmp_host_unregister.argtypes = [_vp]
     L.kidmp_set_host_chunk.restype = C.c_int
     L.kidmp_set_host_chunk.argtypes = [_vp, C.c_int64]
     L.kidmp_init_seconds.restype = C.c_double

@@ -36,8 +36,9 @@ def _state(name, ncol):
     return {k: np.ascontiguousarray(st[k]) for k in KEYS}
 
 
-@pytest.mark.parametrize("kind", ["pageable", "pinned", "registered"])
-@pytest.mark.parametrize("name,chunk", [("mixed", 0), ("mixed", 1024), ("mixed", 700), ("warm", 256)])
+@pytest.mark.parametrize("name,chunk,kind", [("mixed", 0, "pageable"), ("mixed", 0, "pinned"), ("mixed", 1024, "pageable"),
+                                             ("mixed", 1024, "pinned"), ("mixed", 700, "pageable"), ("mixed", 700, "pinned"),
+                                             ("warm", 256, "pageable"), ("warm", 256, "pinned")])
 def test_host_entry_equals_device_entry(gpu_mixed, gpu_warm, name, chunk, kind):
     m = gpu_mixed if name == "mixed" else gpu_warm
     ncol = 4500                                              # default chunking: 4 chunks of 1280, the last one ragged
@@ -49,18 +50,11 @@ def test_host_entry_equals_device_entry(gpu_mixed, gpu_warm, name, chunk, kind):
     else:
         got = {k: st[k].copy() for k in KEYS}
         ppt = np.zeros((ncol, 4))
-    L = thompson.load_library()
-    if kind == "registered":
-        for k in KEYS:
-            assert L.kidmp_host_register(got[k].ctypes.data_as(C.c_void_p), got[k].nbytes) == 0
     try:
         m.set_host_chunk(chunk)
         m.batch_step_host(got, 10.0, ppt=ppt)
     finally:
         m.set_host_chunk(0)
-        if kind == "registered":
-            for k in KEYS:
-                assert L.kidmp_host_unregister(got[k].ctypes.data_as(C.c_void_p)) == 0
     for k in STATE_NAMES:
         assert np.array_equal(got[k], ref[k]), k
     assert np.array_equal(ppt, ref_ppt)
@@ -147,7 +141,6 @@ def test_host_chunk_argument_checks(gpu_mixed):
     L = thompson.load_library()
     assert L.kidmp_set_host_chunk(gpu_mixed._h, -1) != 0
     assert L.kidmp_set_host_chunk(None, 16) != 0
-    assert L.kidmp_host_register(None, 16) != 0
 
 
 def test_aerosol_aware_context_uploads_the_updraft(gpu_mixed_aero):
