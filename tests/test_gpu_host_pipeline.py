@@ -222,3 +222,26 @@ def test_aerosol_aware_context_refuses_missing_aerosols(gpu_mixed_aero):
     st = _state("mixed", 64)
     with pytest.raises(KidmpError, match="aerosol-aware context needs"):
         gpu_mixed_aero.batch_step_host({k: st[k].copy() for k in KEYS if k not in ("nc", "nwfa", "nifa")}, 10.0)
+
+
+@pytest.mark.parametrize("nz,ncol", [(77, 2300), (200, 2100), (120, 1), (33, 5000)])
+def test_other_shapes_through_the_pipeline(gpu_mixed, nz, ncol):
+    """Other level counts (other kernel instantiations, other slice sizes) and degenerate batches."""
+    base = cases.config3(ncol, seed=cases.SEED + 3)
+    if nz <= 120:
+        st = {k: np.ascontiguousarray(base[k][:, :nz]) for k in KEYS}
+    else:                                                    # taller column: the profile repeated upwards
+        reps = (nz + 119) // 120
+        st = {k: np.ascontiguousarray(np.tile(base[k], (1, reps))[:, :nz]) for k in KEYS}
+    ref, ref_ppt, _, _ = _device_reference(gpu_mixed, st, 10.0, False)
+    got = {k: thompson.host_pinned_copy(st[k]) for k in KEYS}
+    ppt, _ = gpu_mixed.batch_step_host(got, 10.0)
+    for k in STATE_NAMES:
+        assert np.array_equal(got[k], ref[k]), k
+    assert np.array_equal(ppt, ref_ppt)
+
+
+def test_empty_batch_is_a_no_op(gpu_mixed):
+    st = {k: np.zeros((0, 120)) for k in KEYS}
+    ppt, _ = gpu_mixed.batch_step_host(st, 10.0)
+    assert ppt.shape == (0, 4)
