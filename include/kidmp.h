@@ -146,10 +146,10 @@ int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt
                               float *ppt, double *rates, int32_t *nstep,
                               int32_t arith, void *stream);
 
-/* Kept for callers of earlier builds: checks its arguments and returns KIDMP_OK.  The device entries own no
- * per-batch device memory (round 1's work profile now lives in LDS): they never allocate, so they can be captured
- * into a hipGraph as they are, and one context may have launches in flight on several streams. */
-int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz);
+/* The device entries own no per-batch device memory and never allocate: they can be captured into a hipGraph as
+ * they are, and one context may have STEP launches in flight on several streams.  (The diagnostics entries further
+ * down -- kidmp_reduce_rates_device, kidmp_sanity_device -- use one scratch buffer per context, allocated by
+ * kidmp_init: they never allocate either, but calls of one of them on ONE context must be enqueued on one stream.) */
 
 /* ---- host memory for the host-array entries (kidmp_batch_step_host*, kidmp32_batch_step_host) ----
  * Those entries stand where the reference's `do i=1,nx` loop works on the model's own arrays (W:54-246), so every
@@ -157,7 +157,7 @@ int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz);
  * three-stage pipeline over column chunks -- upload of chunk i+1, step of chunk i, download of chunk i-1 on three
  * streams -- which only overlaps if the DMA engines can reach the host arrays, i.e. if they are page-locked.
  * kidmp_host_alloc returns page-locked memory (NULL on failure, message in kidmp_last_error(NULL)); free it with
- * kidmp_host_free (memory the caller page-locked itself -- hipHostMalloc, hipHostRegister -- serves as well).  Pageable
+ * kidmp_host_free (memory the caller got from hipHostMalloc serves as well; for hipHostRegister see INTEGRATION.md 4).  Pageable
  * arrays are accepted too: results are the same, the copies are then staged by the HIP runtime and do not overlap.
  * Neither function needs a context. */
 void *kidmp_host_alloc(size_t bytes);
@@ -179,6 +179,39 @@ int kidmp_default_aerosols_device(kidmp_ctx *ctx, int64_t n,
 int kidmp_reduce_ppt_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt,
                             double *out4, void *stream);
 
+/* The same four sums EXACTLY, whatever the order of the additions and however the columns are spread over devices:
+ * limbs (device, int64[KIDMP_PPT_LIMBS]) receives fixed-point accumulators (per species 6 limbs, limb j weighs
+ * 2**(32j-128); values below 2**-128 are dropped, |x| must stay below 2**32).  Integer sums are associative, so
+ * multi-GPU callers all-reduce(SUM, int64) the limbs and every partition of the columns yields the same bits;
+ * kidmp_ppt_limbs_to_sums turns (host) limbs into the four doubles. */
+#define KIDMP_PPT_LIMBS 24
+int kidmp_reduce_ppt_exact_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt, int64_t *limbs, void *stream);
+int kidmp_ppt_limbs_to_sums(const int64_t *limbs, double *out4);
+
+/* ---- several GPUs behind one call: the `do i=1,nx` loop of the KiD adapter (W:54-246) over a device list ----
+ * The reference's compiled-out decomposition (M:3744-3746, M:3813-3819) splits work over MPI ranks; KiD itself is one
+ * process.  kidmp_init_multi builds one context per entry of devices[] (thompson_init on every device, tables built per
+ * device); kidmp_batch_step_host_multi cuts the ncol host columns into contiguous ranges (kidmp_shard_bounds: sizes
+ * differ by at most one, range i on devices[i]), runs every range through its context's own upload / step / download
+ * pipeline concurrently (one host thread per context), and returns in precip_sums[4] (may be NULL) the domain sums of
+ * ppt -- the numerators of the nx-means of W:248-303 -- reduced over the devices with ONE RCCL all-reduce (int64 SUM of
+ * the exact accumulators above; librccl.so is dlopen'ed by kidmp_init_multi, a one-GPU host never needs it).  No halo,
+ * no other exchange.  Results per column are those of kidmp_batch_step_host_diag bit for bit, the sums are identical
+ * for every device list.  A device may be named twice (two contexts on one card).  Optional arrays as above. */
+typedef struct kidmp_multi kidmp_multi;
+int kidmp_init_multi(const kidmp_cfg *cfg, int32_t ndev, const int32_t *devices, kidmp_multi **out);   /* cfg->device is ignored */
+void kidmp_finalize_multi(kidmp_multi *m);
+const char *kidmp_multi_last_error(const kidmp_multi *m);
+int32_t kidmp_multi_size(const kidmp_multi *m);
+kidmp_ctx *kidmp_multi_context(kidmp_multi *m, int32_t i);         /* e.g. for kidmp_load_table_cache on every device */
+int kidmp_shard_bounds(int64_t ncol, int32_t nshard, int32_t shard, int64_t *lo, int64_t *hi);   /* no GPU needed */
+int kidmp_batch_step_host_multi(kidmp_multi *m, int64_t ncol, int32_t nz, double dt,
+                                double *qv, double *qc, double *qi, double *qr,
+                                double *qs, double *qg, double *ni, double *nr,
+                                double *nc, double *nwfa, double *nifa, double *t,
+                                const double *p, const double *w, const double *dz,
+                                double *ppt, double *rates, int32_t *nstep, double *precip_sums);
+
 /* Optional domain diagnostics beyond the four precipitation sums.
  * kidmp_reduce_rates_device: out[KIDMP_NRATES*nz] (device) = sum over columns of rates[col][r][k] -- the mean
  *   process-rate profiles KiD plots are these sums / ncol (save_dg(k, value, ...) of M:2967-3119, averaged over nx);
@@ -186,7 +219,8 @@ int kidmp_reduce_ppt_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt,
  * kidmp_sanity_device: the scan the scheme's own 3-D driver runs after each column (M:1025-1094):
  *   out15[0..6] = max over all n = ncol*nz entries of qc, qr, nr, qs, qi, qg, ni; out15[7..14] = how many entries of
  *   qc, qr, nr, qs, qi, qg, ni, qv are negative (the reference formats a WARNING for each).  Multi-GPU callers
- *   all-reduce(MAX) the first seven and all-reduce(SUM) the rest. */
+ *   all-reduce(MAX) the first seven and all-reduce(SUM) the rest.
+ * Both use per-context scratch from kidmp_init (see above): per context, enqueue them on one stream. */
 int kidmp_reduce_rates_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, const double *rates, double *out, void *stream);
 int kidmp_sanity_device(kidmp_ctx *ctx, int64_t n, const double *qc, const double *qr, const double *nr,
                         const double *qs, const double *qi, const double *qg, const double *ni, const double *qv,

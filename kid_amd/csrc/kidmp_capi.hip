@@ -3,6 +3,9 @@
 // (M:374, M:1156) plus the batched form of the KiD adapter loop (W:54-246).
 #include <hip/hip_runtime.h>
 
+#include <rccl/rccl.h>              // types only: the library is dlopen'ed by kidmp_init_multi (a one-GPU host needs no RCCL)
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kidmp.h"
@@ -47,6 +51,8 @@ struct kidmp_ctx {
     double *d_red = nullptr;
     size_t red_elems = 0;
     unsigned long long *d_sanity = nullptr;
+    // exact (fixed-point) domain sums of the surface precipitation: KIDMP_PPT_LIMBS 64-bit accumulators
+    unsigned long long *d_acc = nullptr;
     std::string fingerprint;
 };
 
@@ -145,6 +151,54 @@ __global__ void k_reduce_ppt(int64_t ncol, const double *__restrict__ ppt, doubl
     if (threadIdx.x < 4) out4[threadIdx.x] = sh[0][threadIdx.x];
 }
 
+// Exact domain sums of ppt[col][0..3] (the nx-means of W:248-303 are these / nx), independent of the order of the
+// additions and therefore of how the columns are sharded over devices or chunks: every value is cut into 32-bit
+// pieces on a fixed-point grid (least significant bit 2**-128, six 64-bit limbs per species, limb j weighs
+// 2**(32 j - 128)) and the pieces are added with integer atomics.  Integer addition is associative, so one GPU, eight
+// GPUs or two contexts on one GPU end with the same 24 limbs, bit for bit; an all-reduce(SUM) of int64 limbs over the
+// devices keeps that.  Range: |x| < 2**32; bits below 2**-128 (3e-39) are dropped; non-finite values are ignored.
+constexpr int ACC_LIMBS = 6, ACC_N = 4 * ACC_LIMBS;
+static_assert(ACC_N == KIDMP_PPT_LIMBS, "include/kidmp.h");
+template <class T>
+__global__ void k_ppt_exact(int64_t ncol, const T *__restrict__ ppt, unsigned long long *__restrict__ acc)
+{
+    __shared__ unsigned long long sh[ACC_N];
+    if (threadIdx.x < ACC_N) sh[threadIdx.x] = 0ull;
+    __syncthreads();
+    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < 4 * ncol; i += int64_t(gridDim.x) * blockDim.x) {
+        const double x = double(ppt[i]);
+        const int sp = int(i & 3);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+        const int e = int((bits >> 52) & 0x7ff);
+        if (e == 0 || e >= 1023 + 32) continue;                       // zero / subnormal: below the grid; >= 2**32, inf, nan: ignored
+        unsigned long long m = (bits & ((1ull << 52) - 1)) | (1ull << 52);   // x = m * 2**(e - 1075)
+        int shft = e - 1075 + 128;                                    // position of m's bit 0 on the grid
+        if (shft < 0) {
+            if (shft <= -53) continue;
+            m >>= -shft;
+            shft = 0;
+        }
+        const int j = shft >> 5, r = shft & 31;                       // shft <= 107: j <= 3, pieces land in limbs j .. j+2 <= 5
+        const unsigned long long lo = m << r, hi = r ? (m >> (64 - r)) : 0ull;
+        unsigned long long pc[3] = {lo & 0xffffffffull, lo >> 32, hi};
+        const bool neg = (bits >> 63) != 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (pc[q]) atomicAdd(&sh[sp * ACC_LIMBS + j + q], neg ? (0ull - pc[q]) : pc[q]);   // two's complement
+    }
+    __syncthreads();
+    if (threadIdx.x < ACC_N && sh[threadIdx.x]) atomicAdd(&acc[threadIdx.x], sh[threadIdx.x]);
+}
+template <class T>
+hipError_t launch_ppt_exact(int64_t ncol, const T *ppt, unsigned long long *acc, hipStream_t s)
+{
+    if (ncol <= 0) return hipSuccess;
+    int64_t g = (4 * ncol + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_ppt_exact<T>, dim3((unsigned)g), dim3(256), 0, s, ncol, ppt, acc);
+    return hipGetLastError();
+}
+
 // Domain sums of the rate diagnostics: part[chunk][r*nz+k] = sum over the chunk's columns (fixed order), then
 // out[r*nz+k] = sum over chunks (fixed order) => bitwise reproducible for a given ncol.
 constexpr int RED_CHUNKS = 128;
@@ -184,9 +238,9 @@ __global__ void k_sanity(int64_t n, SanityPtrs p, unsigned long long *acc)
         for (int a = 0; a < 8; ++a) {
             const double x = p.v[a][i];
             if (x < 0.) ++neg[a];
-            else if (a < 7) {
+            else if (a < 7 && x > 0.) {                       // +-0 and NaN are no candidates (-0.0 has the largest bit pattern)
                 const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-                mx[a] = b > mx[a] && x == x ? b : mx[a];
+                mx[a] = b > mx[a] ? b : mx[a];
             }
         }
     }
@@ -363,7 +417,7 @@ struct PipelineDrain {
 
 template <class T, class Launch>
 int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const *io, const T *const *in, T *ppt,
-                  double *rates, int32_t *nstep, Launch launch)
+                  double *rates, int32_t *nstep, Launch launch, bool exact_sums = false)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
     // Arrays the caller may leave out (NULL), as KiD itself does (W:36 passes nc1d, nwfa1d, nifa1d unset; a warm run
@@ -387,7 +441,13 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
     ptrs[np++] = in[0]; ptrs[np++] = in[1]; ptrs[np++] = ppt;
     if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, np)) return rc;
     if (has_w && !in[2] && ncol > 0) return fail(ctx, KIDMP_EINVAL, "kidmp: an aerosol-aware context needs the updraft profile w");
-    if (ncol == 0) return KIDMP_OK;
+    if (ncol == 0) {
+        if (exact_sums) {
+            GUARD(ctx);
+            HIPTRY(ctx, hipMemset(ctx->d_acc, 0, ACC_N * sizeof(unsigned long long)));
+        }
+        return KIDMP_OK;
+    }
     GUARD(ctx);
     const int64_t CH = pick_host_chunk(ctx, ncol);
     const int64_t nchunk = (ncol + CH - 1) / CH;
@@ -410,6 +470,7 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
     }
     char *const base = reinterpret_cast<char *>(ctx->d_stage);
     PipelineDrain drain{ctx};
+    if (exact_sums) HIPTRY(ctx, hipMemsetAsync(ctx->d_acc, 0, ACC_N * sizeof(unsigned long long), ctx->stream));
     for (int64_t i = 0; i < nchunk; ++i) {
         const int b = int(i % nbuf);
         const int64_t c0 = i * CH, n = (c0 + CH <= ncol ? CH : ncol - c0);
@@ -441,6 +502,7 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
             HIPTRY(ctx, hipGetLastError());
         }
         if (int rc = launch(n, dio, din, dppt, drates, dnstep)) return rc;
+        if (exact_sums) HIPTRY(ctx, launch_ppt_exact<T>(n, dppt, ctx->d_acc, ctx->stream));   // the chunk's share of the domain sums
         HIPTRY(ctx, hipEventRecord(ctx->ev_step[b], ctx->stream));
         // download
         HIPTRY(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->ev_step[b], 0));
@@ -511,6 +573,11 @@ int kidmp_init(const kidmp_cfg *cfg, kidmp_ctx **out)
         INITTRY(hipEventCreateWithFlags(&c->ev_step[b], hipEventDisableTiming));
         INITTRY(hipEventCreateWithFlags(&c->ev_down[b], hipEventDisableTiming));
     }
+    // scratch of the diagnostics entries, sized for KIDMP_MAX_NZ once: no entry allocates after kidmp_init
+    c->red_elems = size_t(RED_CHUNKS) * size_t(KIDMP_NRATES) * size_t(KIDMP_MAX_NZ);
+    INITTRY(hipMalloc((void **)&c->d_red, c->red_elems * sizeof(double)));
+    INITTRY(hipMalloc((void **)&c->d_sanity, 15 * sizeof(unsigned long long)));
+    INITTRY(hipMalloc((void **)&c->d_acc, ACC_N * sizeof(unsigned long long)));
     INITTRY(hipMalloc((void **)&c->d_consts, sizeof(Consts)));
     INITTRY(hipMalloc((void **)&c->d_bins, sizeof(Bins)));
     INITTRY(hipMemcpy(c->d_consts, &c->hc, sizeof(Consts), hipMemcpyHostToDevice));
@@ -539,6 +606,7 @@ void kidmp_finalize(kidmp_ctx *c)
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_red) (void)hipFree(c->d_red);
     if (c->d_sanity) (void)hipFree(c->d_sanity);
+    if (c->d_acc) (void)hipFree(c->d_acc);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->s_h2d) (void)hipStreamDestroy(c->s_h2d);
     if (c->s_d2h) (void)hipStreamDestroy(c->s_d2h);
@@ -579,13 +647,6 @@ int kidmp_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt,
     if (ncol == 0) return KIDMP_OK;
     HIPTRY(ctx, p64::launch_column_step(a, (hipStream_t)stream));
     return KIDMP_OK;
-}
-
-int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
-{
-    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
-    if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return fail(ctx, KIDMP_EINVAL, "kidmp_reserve: bad argument");
-    return KIDMP_OK;                                         // the column step owns no per-batch device memory any more
 }
 
 void *kidmp_host_alloc(size_t bytes)
@@ -746,13 +807,7 @@ int kidmp_reduce_rates_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, const do
     if (int rc = check_on_device(ctx, rates, "rates")) return rc;
     if (int rc = check_on_device(ctx, out, "out")) return rc;
     const int n = KIDMP_NRATES * nz;
-    const size_t need = size_t(RED_CHUNKS) * size_t(n);
-    if (need > ctx->red_elems) {
-        if (ctx->d_red) (void)hipFree(ctx->d_red);
-        ctx->d_red = nullptr; ctx->red_elems = 0;
-        HIPTRY(ctx, hipMalloc((void **)&ctx->d_red, need * sizeof(double)));
-        ctx->red_elems = need;
-    }
+    if (size_t(RED_CHUNKS) * size_t(n) > ctx->red_elems) return fail(ctx, KIDMP_EINVAL, "kidmp_reduce_rates_device: nz beyond KIDMP_MAX_NZ");
     const int T = 128;
     hipLaunchKernelGGL(k_reduce_rates_part, dim3((n + T - 1) / T, RED_CHUNKS), dim3(T), 0, (hipStream_t)stream, ncol, n, rates, ctx->d_red);
     hipLaunchKernelGGL(k_reduce_rates_final, dim3((n + T - 1) / T), dim3(T), 0, (hipStream_t)stream, n, ctx->d_red, out);
@@ -768,7 +823,6 @@ int kidmp_sanity_device(kidmp_ctx *ctx, int64_t n, const double *qc, const doubl
     GUARD(ctx);
     if (int rc = check_on_device(ctx, qc, "qc")) return rc;
     if (int rc = check_on_device(ctx, out15, "out15")) return rc;
-    if (!ctx->d_sanity) HIPTRY(ctx, hipMalloc((void **)&ctx->d_sanity, 15 * sizeof(unsigned long long)));
     hipStream_t s = (hipStream_t)stream;
     HIPTRY(ctx, hipMemsetAsync(ctx->d_sanity, 0, 15 * sizeof(unsigned long long), s));
     if (n > 0) {
@@ -889,6 +943,242 @@ int kidmp_load_table_cache(kidmp_ctx *ctx, const char *dir)
             HIPTRY(ctx, hipMemcpy(fam.dev[i], host[i].data(), size_t(fam.n) * sizeof(double), hipMemcpyHostToDevice));
     }
     HIPTRY(ctx, repack_records(ctx->tables, ctx->stream));       // the solver reads the interleaved records
+    return KIDMP_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// Several GPUs behind one call: what a Fortran / C host (KiD's `do i=1,nx`, W:54-246, with nx in the millions) reaches
+// without MPI.  Columns are independent and the tables read-only, so the batch is cut into contiguous ranges, one per
+// context (= per device), each range goes through that context's own upload / step / download pipeline on its own host
+// thread, and the ONE exchange of the path -- the domain sums of the surface precipitation, the nx-means of W:248-303
+// -- is an RCCL all-reduce over the devices of the exact integer accumulators (k_ppt_exact): 24 int64, SUM.
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+
+const char *load_rccl()       // nullptr on success, else what failed
+{
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (g_rccl.lib) return nullptr;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return "librccl.so not found (dlopen)";
+    RcclApi a;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(h, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(h, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(h, "ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString)
+        return "librccl.so lacks an expected symbol";
+    a.lib = h;
+    g_rccl = a;
+    return nullptr;
+}
+
+}  // namespace
+
+struct kidmp_multi {
+    std::vector<kidmp_ctx *> ctx;            // one per entry of the device list, in list order
+    std::vector<int> leader;                 // contexts that lead a distinct device (entries may repeat a device)
+    std::vector<int> leader_of;              // ctx index -> index into `leader`
+    std::vector<ncclComm_t> comm;            // one RCCL communicator per distinct device
+    std::string err;
+};
+
+namespace {
+
+int mfail(kidmp_multi *m, int code, const std::string &msg)
+{
+    if (m) m->err = msg;
+    g_err = msg;
+    return code;
+}
+
+// the 24 limbs -> four doubles: carries propagated in 128-bit integers, then the digits summed from the top in long
+// double (64-bit significand): a pure function of the limbs, so equal limbs give equal sums
+void limbs_to_sums(const int64_t *limbs, double *out4)
+{
+    for (int sp = 0; sp < 4; ++sp) {
+        __int128 carry = 0;
+        long double v = 0.0L;
+        long double digit[ACC_LIMBS + 1];
+        for (int j = 0; j < ACC_LIMBS; ++j) {
+            const __int128 t = (__int128)limbs[sp * ACC_LIMBS + j] + carry;
+            const __int128 lowbits = t & (__int128)0xffffffffLL;           // 0 .. 2**32-1
+            carry = (t - lowbits) >> 32;                                   // exact: t - lowbits is a multiple of 2**32
+            digit[j] = (long double)(int64_t)lowbits;
+        }
+        digit[ACC_LIMBS] = (long double)(int64_t)carry;                    // signed top
+        for (int j = ACC_LIMBS; j >= 0; --j) v += __builtin_ldexpl(digit[j], 32 * j - 128);
+        out4[sp] = (double)v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int kidmp_shard_bounds(int64_t ncol, int32_t nshard, int32_t shard, int64_t *lo, int64_t *hi)
+{
+    if (ncol < 0 || nshard < 1 || shard < 0 || shard >= nshard || !lo || !hi) return fail(nullptr, KIDMP_EINVAL, "kidmp_shard_bounds: bad argument");
+    const int64_t base = ncol / nshard, rem = ncol % nshard;               // contiguous ranges, sizes differ by at most one
+    *lo = shard * base + (shard < rem ? shard : rem);
+    *hi = *lo + base + (shard < rem ? 1 : 0);
+    return KIDMP_OK;
+}
+
+int kidmp_ppt_limbs_to_sums(const int64_t *limbs, double *out4)
+{
+    if (!limbs || !out4) return fail(nullptr, KIDMP_EINVAL, "kidmp_ppt_limbs_to_sums: null argument");
+    limbs_to_sums(limbs, out4);
+    return KIDMP_OK;
+}
+
+int kidmp_reduce_ppt_exact_device(kidmp_ctx *ctx, int64_t ncol, const double *ppt, int64_t *limbs, void *stream)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (ncol < 0 || !limbs || (ncol > 0 && !ppt)) return fail(ctx, KIDMP_EINVAL, "kidmp_reduce_ppt_exact_device: bad argument");
+    GUARD(ctx);
+    if (int rc = check_on_device(ctx, ppt, "ppt")) return rc;
+    if (int rc = check_on_device(ctx, limbs, "limbs")) return rc;
+    HIPTRY(ctx, hipMemsetAsync(limbs, 0, ACC_N * sizeof(int64_t), (hipStream_t)stream));
+    HIPTRY(ctx, launch_ppt_exact<double>(ncol, ppt, reinterpret_cast<unsigned long long *>(limbs), (hipStream_t)stream));
+    return KIDMP_OK;
+}
+
+void kidmp_finalize_multi(kidmp_multi *m)
+{
+    if (!m) return;
+    for (ncclComm_t c : m->comm)
+        if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
+    for (kidmp_ctx *c : m->ctx) kidmp_finalize(c);
+    delete m;
+}
+
+int kidmp_init_multi(const kidmp_cfg *cfg, int32_t ndev, const int32_t *devices, kidmp_multi **out)
+{
+    if (!cfg || !out || !devices || ndev < 1 || ndev > MAX_CONST_SLOTS) return fail(nullptr, KIDMP_EINVAL, "kidmp_init_multi: bad argument (1..8 devices)");
+    *out = nullptr;
+    kidmp_multi *m = new (std::nothrow) kidmp_multi;
+    if (!m) return fail(nullptr, KIDMP_ENOMEM, "kidmp_init_multi: out of host memory");
+    for (int i = 0; i < ndev; ++i) {
+        kidmp_cfg c = *cfg;
+        c.device = devices[i];
+        kidmp_ctx *x = nullptr;
+        const int rc = kidmp_init(&c, &x);
+        if (rc != KIDMP_OK) { kidmp_finalize_multi(m); return rc; }          // message already in g_err
+        m->ctx.push_back(x);
+        int l = -1;
+        for (size_t q = 0; q < m->leader.size(); ++q)
+            if (m->ctx[m->leader[q]]->cfg.device == devices[i]) l = int(q);
+        if (l < 0) { m->leader.push_back(i); l = int(m->leader.size()) - 1; }
+        m->leader_of.push_back(l);
+    }
+    // RCCL: one communicator per DISTINCT device (a list may name a device twice -- two contexts sharing a card, which
+    // is how a one-GPU box exercises this path; their accumulators are added before the collective)
+    if (const char *why = load_rccl()) { kidmp_finalize_multi(m); return fail(nullptr, KIDMP_ENODEV, std::string("kidmp_init_multi: ") + why); }
+    std::vector<int> devs;
+    for (int l : m->leader) devs.push_back(m->ctx[l]->cfg.device);
+    m->comm.assign(devs.size(), nullptr);
+    const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), int(devs.size()), devs.data());
+    if (r != ncclSuccess) {
+        const std::string msg = std::string("kidmp_init_multi: ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+        for (auto &c : m->comm) c = nullptr;
+        kidmp_finalize_multi(m);
+        return fail(nullptr, KIDMP_EHIP, msg);
+    }
+    *out = m;
+    return KIDMP_OK;
+}
+
+int32_t kidmp_multi_size(const kidmp_multi *m) { return m ? int32_t(m->ctx.size()) : 0; }
+kidmp_ctx *kidmp_multi_context(kidmp_multi *m, int32_t i) { return m && i >= 0 && size_t(i) < m->ctx.size() ? m->ctx[size_t(i)] : nullptr; }
+const char *kidmp_multi_last_error(const kidmp_multi *m) { return m && !m->err.empty() ? m->err.c_str() : g_err.c_str(); }
+
+int kidmp_batch_step_host_multi(kidmp_multi *m, int64_t ncol, int32_t nz, double dt,
+                                double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
+                                double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
+                                const double *p, const double *w, const double *dz, double *ppt, double *rates,
+                                int32_t *nstep, double *precip_sums)
+{
+    if (!m || m->ctx.empty()) return mfail(m, KIDMP_ESTATE, "kidmp_batch_step_host_multi: not initialised");
+    if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return mfail(m, KIDMP_EINVAL, "kidmp_batch_step_host_multi: bad ncol / nz");
+    const int nctx = int(m->ctx.size());
+    std::vector<int> rc(size_t(nctx), KIDMP_OK);
+    std::vector<std::string> msg{size_t(nctx)};
+    auto work = [&](int i) {
+        int64_t lo = 0, hi = 0;
+        kidmp_shard_bounds(ncol, nctx, i, &lo, &hi);
+        const size_t o = size_t(lo) * size_t(nz);
+        auto at = [o](double *a) { return a ? a + o : nullptr; };
+        auto atc = [o](const double *a) { return a ? a + o : nullptr; };
+        kidmp_ctx *c = m->ctx[size_t(i)];
+        double *io[12] = {at(qv), at(qc), at(qi), at(qr), at(qs), at(qg), at(ni), at(nr), at(nc), at(nwfa), at(nifa), at(t)};
+        const double *in[3] = {atc(p), atc(dz), atc(w)};
+        rc[size_t(i)] = host_pipeline<double>(c, hi - lo, nz, dt, io, in, ppt ? ppt + 4 * lo : nullptr,
+            rates ? rates + size_t(KIDMP_NRATES) * o : nullptr, nstep ? nstep + 4 * lo : nullptr,
+            [&](int64_t n, double *const *d, const double *const *f, double *dppt, double *drates, int32_t *dnstep) {
+                return kidmp_batch_step_device(c, n, nz, dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11],
+                                               f[0], f[2], f[1], dppt, drates, dnstep, c->stream);
+            }, true);
+        if (rc[size_t(i)] != KIDMP_OK) msg[size_t(i)] = kidmp_last_error(c);
+    };
+    // one host thread per context: HIP's current device and the pipeline's blocking waits are per thread
+    std::vector<std::thread> th;
+    for (int i = 1; i < nctx; ++i) th.emplace_back(work, i);
+    work(0);
+    for (auto &x : th) x.join();
+    for (int i = 0; i < nctx; ++i)
+        if (rc[size_t(i)] != KIDMP_OK) return mfail(m, rc[size_t(i)], "device " + std::to_string(m->ctx[size_t(i)]->cfg.device) + ": " + msg[size_t(i)]);
+    if (!precip_sums) return KIDMP_OK;
+    // ---- the domain sums: contexts that share a device add their limbs, then ONE all-reduce over the devices ----
+    std::vector<int64_t> limbs(size_t(nctx) * ACC_N), lead(m->leader.size() * ACC_N, 0);
+    for (int i = 0; i < nctx; ++i) {
+        kidmp_ctx *c = m->ctx[size_t(i)];
+        DeviceGuard g(c->cfg.device);
+        const hipError_t e = hipMemcpy(&limbs[size_t(i) * ACC_N], c->d_acc, ACC_N * sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("hipMemcpy(limbs): ") + hipGetErrorString(e));
+        for (int q = 0; q < ACC_N; ++q)                                    // wrap-around addition == two's complement sum
+            lead[size_t(m->leader_of[size_t(i)]) * ACC_N + q] = int64_t(uint64_t(lead[size_t(m->leader_of[size_t(i)]) * ACC_N + q]) + uint64_t(limbs[size_t(i) * ACC_N + q]));
+    }
+    for (size_t l = 0; l < m->leader.size(); ++l) {
+        kidmp_ctx *c = m->ctx[size_t(m->leader[l])];
+        DeviceGuard g(c->cfg.device);
+        const hipError_t e = hipMemcpyAsync(c->d_acc, &lead[l * ACC_N], ACC_N * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("hipMemcpyAsync(limbs): ") + hipGetErrorString(e));
+    }
+    ncclResult_t r = g_rccl.GroupStart();
+    for (size_t l = 0; l < m->leader.size() && r == ncclSuccess; ++l) {
+        kidmp_ctx *c = m->ctx[size_t(m->leader[l])];
+        DeviceGuard g(c->cfg.device);
+        r = g_rccl.AllReduce(c->d_acc, c->d_acc, ACC_N, ncclInt64, ncclSum, m->comm[l], c->stream);
+    }
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return mfail(m, KIDMP_EHIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
+    int64_t total[ACC_N];
+    for (size_t l = 0; l < m->leader.size(); ++l) {                        // every device holds the same sums; all are drained
+        kidmp_ctx *c = m->ctx[size_t(m->leader[l])];
+        DeviceGuard g(c->cfg.device);
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && l == 0) e = hipMemcpy(total, c->d_acc, sizeof(total), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("all-reduce of the precipitation sums: ") + hipGetErrorString(e));
+    }
+    limbs_to_sums(total, precip_sums);
     return KIDMP_OK;
 }
 

@@ -73,27 +73,31 @@ class ShardedColumns:
         torch.cuda.synchronize(self.device)
 
     def diagnostics(self, group=None, cpu_collective=False, want_sanity=True):
-        """Domain diagnostics over ALL ranks: dict(precip=[4] sums, sanity=[15] (7 maxima, 8 negative counts),
-        rates=[36, nz] sums or None).  One RCCL all-gather of the per-rank vectors, reduced locally (SUM, and MAX for
+        """Domain diagnostics over ALL ranks: dict(precip=[4] sums, precip_limbs=int64 [24] exact accumulators they
+        come from, sanity=[15] (7 maxima, 8 negative counts), rates=[36, nz] sums or None).  One RCCL all-gather of the per-rank vectors, reduced locally (SUM, and MAX for
         the maxima); cpu_collective=True moves them to the host first (gloo rehearsals).  want_sanity=False leaves the
         max-q / negative-value scan out (the optional debugging aid of SURVEY 8e; it reads eight state arrays) and
         returns zeros in its place: what remains is the reference adapter's own exchange, the precipitation means of
         W:248-303."""
         import torch
         import torch.distributed as dist
-        if self.arith == "p64":
-            precip = self.model.reduce_ppt(self.ppt)
-            sanity = self.model.sanity(self.st) if want_sanity else torch.zeros(15, dtype=torch.float64, device=precip.device)
-        else:                                                  # the diagnostics kernels are binary64: convert the shard's view
-            precip = self.model.reduce_ppt(self.ppt.double())
-            sanity = (self.model.sanity({k: self.st[k].double() for k in self.model.SANITY_NEG}) if want_sanity
-                      else torch.zeros(15, dtype=torch.float64, device=precip.device))
+        from .thompson import PPT_LIMBS, limbs_to_sums
+        # precipitation: exact fixed-point accumulators (int64 limbs) -- integer sums are associative, so the reduced
+        # domain sums are the same bits for every world size and every partition of the columns
+        ppt64 = self.ppt if self.arith == "p64" else self.ppt.double()        # the diagnostics kernels are binary64
+        limbs = self.model.reduce_ppt_exact(ppt64)
+        if want_sanity:
+            sanity = self.model.sanity(self.st if self.arith == "p64" else {k: self.st[k].double() for k in self.model.SANITY_NEG})
+        else:
+            sanity = torch.zeros(15, dtype=torch.float64, device=limbs.device)
         rates = self.model.reduce_rates(self.rates) if self.rates is not None else None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            # ONE collective: every rank contributes its [4 + 15 (+ 36 nz)] vector, the sums and maxima are then formed
-            # locally in rank order (identical on all ranks).  <= 34.8 KB per rank: latency-bound whatever the links.
+            # ONE collective: every rank contributes its [24 limbs (bit patterns) + 15 (+ 36 nz)] vector; the sums and
+            # maxima are then formed locally in rank order (identical on all ranks).  <= 35 KB per rank: latency-bound
+            # whatever the links.  An all-gather moves bits, it does no arithmetic: the int64 limbs ride along as the
+            # bit patterns of float64 slots.
             world = dist.get_world_size(group)
-            parts = [precip, sanity] + ([rates.reshape(-1)] if rates is not None else [])
+            parts = [limbs.view(torch.float64), sanity] + ([rates.reshape(-1)] if rates is not None else [])
             mine = torch.cat(parts)
             if cpu_collective:
                 mine = mine.cpu()
@@ -101,11 +105,13 @@ class ShardedColumns:
             with torch.cuda.device(self.device):
                 dist.all_gather_into_tensor(gathered, mine, group=group)
             g = gathered.view(world, -1)
-            precip = g[:, 0:4].sum(dim=0)
-            sanity = torch.cat([g[:, 4:11].max(dim=0).values, g[:, 11:19].sum(dim=0)])
+            limbs = g[:, 0:PPT_LIMBS].contiguous().view(torch.int64).sum(dim=0)          # wrap-around int64 sum
+            o = PPT_LIMBS
+            sanity = torch.cat([g[:, o:o + 7].max(dim=0).values, g[:, o + 7:o + 15].sum(dim=0)])
             if rates is not None:
-                rates = g[:, 19:].sum(dim=0).view(rates.shape)
-        return dict(precip=precip, sanity=sanity, rates=rates)
+                rates = g[:, o + 15:].sum(dim=0).view(rates.shape)
+        precip = torch.from_numpy(limbs_to_sums(limbs.cpu().numpy())).to(sanity.device)
+        return dict(precip=precip, precip_limbs=limbs, sanity=sanity, rates=rates)
 
     def close(self):
         self.model.close()

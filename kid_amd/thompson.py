@@ -27,6 +27,7 @@ RATE_NAMES = (
 ).split()                                                                                      # M:2967-3119
 NRATES = 36
 MAX_NZ = 256
+PPT_LIMBS = 24            # KIDMP_PPT_LIMBS: exact precipitation accumulators (include/kidmp.h)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -94,8 +95,24 @@ def load_library(path=None):
     L.kidmp_effective_radii_device.argtypes = [_vp, C.c_int64] + [_vp] * 11 + [_vp]
     L.kidmp_kernel_fingerprint.restype = C.c_char_p
     L.kidmp_kernel_fingerprint.argtypes = [_vp]
-    L.kidmp_reserve.restype = C.c_int
-    L.kidmp_reserve.argtypes = [_vp, C.c_int64, C.c_int32]
+    L.kidmp_reduce_ppt_exact_device.restype = C.c_int
+    L.kidmp_reduce_ppt_exact_device.argtypes = [_vp, C.c_int64, _vp, _vp, _vp]
+    L.kidmp_ppt_limbs_to_sums.restype = C.c_int
+    L.kidmp_ppt_limbs_to_sums.argtypes = [C.POINTER(C.c_int64), _dp]
+    L.kidmp_shard_bounds.restype = C.c_int
+    L.kidmp_shard_bounds.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.kidmp_init_multi.restype = C.c_int
+    L.kidmp_init_multi.argtypes = [C.POINTER(_Cfg), C.c_int32, C.POINTER(C.c_int32), C.POINTER(_vp)]
+    L.kidmp_finalize_multi.restype = None
+    L.kidmp_finalize_multi.argtypes = [_vp]
+    L.kidmp_multi_last_error.restype = C.c_char_p
+    L.kidmp_multi_last_error.argtypes = [_vp]
+    L.kidmp_multi_size.restype = C.c_int32
+    L.kidmp_multi_size.argtypes = [_vp]
+    L.kidmp_multi_context.restype = _vp
+    L.kidmp_multi_context.argtypes = [_vp, C.c_int32]
+    L.kidmp_batch_step_host_multi.restype = C.c_int
+    L.kidmp_batch_step_host_multi.argtypes = [_vp, C.c_int64, C.c_int32, C.c_double] + [_dp] * 17 + [C.POINTER(C.c_int32), _dp]
     L.kidmp_math_probe.restype = C.c_int
     L.kidmp_math_probe.argtypes = [_vp, C.c_int32, C.c_int64, _dp, _dp, _dp]
     L.kidmp_get_table.restype = C.c_int64
@@ -319,10 +336,6 @@ class ThompsonMP:
         """Columns per pipeline chunk of the host-array entries (0 = default)."""
         self._check(load_library().kidmp_set_host_chunk(self._h, int(ncol_per_chunk)))
 
-    def reserve(self, ncol, nz):
-        """Pre-size the context's work buffer: later batch_step calls of that size never allocate (graph capture)."""
-        self._check(load_library().kidmp_reserve(self._h, ncol, nz))
-
     def reduce_ppt(self, ppt, stream=None):
         """Domain sums of the surface precipitation on the device (W:248-275 analogue)."""
         import torch
@@ -330,6 +343,17 @@ class ThompsonMP:
         out = torch.empty(4, dtype=torch.float64, device=ppt.device)
         s = stream if stream is not None else torch.cuda.current_stream(ppt.device).cuda_stream
         self._check(load_library().kidmp_reduce_ppt_device(self._h, ppt.shape[0], ppt.data_ptr(), out.data_ptr(), s))
+        return out
+
+    def reduce_ppt_exact(self, ppt, stream=None):
+        """The same four sums as exact fixed-point accumulators: int64 [PPT_LIMBS] on the device.  Integer sums are
+        associative: multi-GPU callers all-reduce(SUM) the limbs and get identical bits for every partition of the
+        columns; limbs_to_sums() converts."""
+        import torch
+        self._want(ppt, torch.float64, (ppt.shape[0], 4), "reduce_ppt_exact: ppt")
+        out = torch.empty(PPT_LIMBS, dtype=torch.int64, device=ppt.device)
+        s = stream if stream is not None else torch.cuda.current_stream(ppt.device).cuda_stream
+        self._check(load_library().kidmp_reduce_ppt_exact_device(self._h, ppt.shape[0], ppt.data_ptr(), out.data_ptr(), s))
         return out
 
     def reduce_rates(self, rates, stream=None):
@@ -413,6 +437,82 @@ class ThompsonMP:
     @staticmethod
     def kernel_name():
         return load_library().kidmp_kernel_name().decode()
+
+
+def limbs_to_sums(limbs):
+    """int64 [PPT_LIMBS] (host: numpy array or CPU tensor) -> the four precipitation domain sums (float64 numpy)."""
+    a = np.ascontiguousarray(np.asarray(limbs, dtype=np.int64))
+    if a.shape != (PPT_LIMBS,):
+        raise KidmpError("limbs_to_sums: expected %d int64 limbs" % PPT_LIMBS)
+    out = np.empty(4)
+    load_library().kidmp_ppt_limbs_to_sums(a.ctypes.data_as(C.POINTER(C.c_int64)), _np_ptr(out))
+    return out
+
+
+def shard_bounds(ncol, nshard, shard):
+    """The library's contiguous column ranges (kidmp_shard_bounds; no GPU needed)."""
+    lo, hi = C.c_int64(), C.c_int64()
+    rc = load_library().kidmp_shard_bounds(int(ncol), int(nshard), int(shard), C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise KidmpError("kidmp_shard_bounds failed (%d): %s" % (rc, load_library().kidmp_last_error(None).decode()))
+    return lo.value, hi.value
+
+
+class ThompsonMulti:
+    """Several GPUs behind one host-array call (kidmp_init_multi / kidmp_batch_step_host_multi): contiguous column
+    ranges over the device list, one pipeline per device on its own host thread, the precipitation domain sums
+    all-reduced with RCCL inside the library.  This is what the Fortran drop-in uses when more than one device is
+    configured; the Python mirror exists for the tests."""
+
+    def __init__(self, devices, iiwarm=False, set_Nc=100.0, l_sediment=True, aerosol_aware=False):
+        self._h = None
+        L = load_library()
+        cfg = _Cfg(int(bool(iiwarm)), int(bool(l_sediment)), float(set_Nc), 0, int(bool(aerosol_aware)))
+        devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+        h = _vp()
+        rc = L.kidmp_init_multi(C.byref(cfg), len(devices), devs, C.byref(h))
+        if rc != 0:
+            raise KidmpError("kidmp_init_multi failed (%d): %s" % (rc, L.kidmp_last_error(None).decode()))
+        self._h = h
+        self.devices = [int(d) for d in devices]
+        self.iiwarm = bool(iiwarm)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load_library().kidmp_finalize_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def batch_step_host(self, st, dt, ppt=None, want_rates=False, want_nstep=False):
+        """numpy float64 [ncol, nz] arrays, in place (optional keys as ThompsonMP.batch_step_host).
+        Returns (ppt, rates or None, nstep or None, precip_sums[4])."""
+        ncol, nz = st["qv"].shape
+        ptrs = []
+        for k in STATE_NAMES + FORCING_NAMES:
+            a = st.get(k)
+            if a is None:
+                ptrs.append(None)
+                continue
+            if not (a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (ncol, nz)):
+                raise KidmpError("batch_step_host: %s must be contiguous float64 [ncol, nz]" % k)
+            ptrs.append(_np_ptr(a))
+        if ppt is None:
+            ppt = np.zeros((ncol, 4))
+        rates = np.zeros((ncol, NRATES, nz)) if want_rates else None
+        nstep = np.zeros((ncol, 4), dtype=np.int32) if want_nstep else None
+        sums = np.zeros(4)
+        L = load_library()
+        rc = L.kidmp_batch_step_host_multi(self._h, ncol, nz, float(dt), *ptrs, _np_ptr(ppt),
+                                           _np_ptr(rates) if want_rates else None,
+                                           nstep.ctypes.data_as(C.POINTER(C.c_int32)) if want_nstep else None, _np_ptr(sums))
+        if rc != 0:
+            raise KidmpError("kidmp_batch_step_host_multi failed (%d): %s" % (rc, L.kidmp_multi_last_error(self._h).decode()))
+        return ppt, rates, nstep, sums
 
 
 # ---- module-level mirror of the Fortran module procedures ----

@@ -1986,16 +1986,18 @@ void P(th_oracle_default_aerosols)(const th_oracle *ctx, int nz,
 
 /* ------------------------------------------------------------------ */
 typedef struct {
-    const th_oracle *o; long c0, c1; int nz; real dt;
+    const th_oracle *o; long ncol, per; int nz; real dt;
     real *qv, *qc, *qi, *qr, *qs, *qg, *ni, *nr, *nc, *nwfa, *nifa, *t;
     const real *p, *w, *dz; real *ppt; int *illcond; int force;
 } batch_job;
 
-static void *batch_worker(void *arg)
+/* one chunk = `per` consecutive columns (handed out dynamically by the pool) */
+static void batch_chunk(void *arg, long chunk)
 {
     batch_job *b = (batch_job *)arg;
     const size_t nz = (size_t)b->nz;
-    for (long c = b->c0; c < b->c1; c++) {
+    const long c0 = chunk * b->per, c1 = c0 + b->per < b->ncol ? c0 + b->per : b->ncol;
+    for (long c = c0; c < c1; c++) {
         size_t off = (size_t)c * nz;
         P(th_oracle_mp_thompson_force)(b->o, b->qv + off, b->qc + off, b->qi + off, b->qr + off,
                                  b->qs + off, b->qg + off, b->ni + off, b->nr + off,
@@ -2003,7 +2005,6 @@ static void *batch_worker(void *arg)
                                  b->p + off, b->w + off, b->dz + off, b->ppt + 4 * (size_t)c,
                                  b->nz, b->dt, NULL, NULL, b->illcond ? b->illcond + off : NULL, b->force);
     }
-    return NULL;
 }
 
 #ifndef TH_P32N
@@ -2039,18 +2040,14 @@ int P(th_oracle_batch_force)(const th_oracle *o, long ncol, int nz, real dt,
                           real *ppt, int nthreads, int *illcond, int force)
 {
     if (nthreads < 1) nthreads = 1;
-    if (nthreads > ncol) nthreads = (int)(ncol > 0 ? ncol : 1);
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
-    batch_job *jb = (batch_job *)malloc(sizeof(batch_job) * nthreads);
-    for (int i = 0; i < nthreads; i++) {
-        batch_job b = { o, ncol * i / nthreads, ncol * (i + 1) / nthreads, nz, dt,
-                        qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt, illcond, force };
-        jb[i] = b;
-        if (nthreads == 1) batch_worker(&jb[i]);
-        else pthread_create(&th[i], NULL, batch_worker, &jb[i]);
-    }
-    if (nthreads > 1) for (int i = 0; i < nthreads; i++) pthread_join(th[i], NULL);
-    free(th); free(jb);
+    if (ncol <= 0) return 0;
+    /* columns go to the persistent pool in chunks of `per`, handed out dynamically: about 8 chunks per thread, so that
+     * columns of unequal cost (substep counts, regimes) balance, and at least 4 columns per chunk */
+    long per = ncol / ((long)nthreads * 8);
+    if (per < 4) per = 4;
+    if (per > 64) per = 64;
+    batch_job b = { o, ncol, per, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt, illcond, force };
+    th_pool_run(nthreads, batch_chunk, &b, (ncol + per - 1) / per);
     return 0;
 }
 

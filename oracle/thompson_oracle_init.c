@@ -15,6 +15,89 @@
 #include <unistd.h>
 
 /* ------------------------------------------------------------------ */
+/* Persistent worker pool (see thompson_oracle_internal.h).  Test infrastructure: it exists so that the CPU baseline
+ * of bench.py measures the restated physics, not pthread_create. */
+#define TH_POOL_MAX 1024
+static struct {
+    pthread_mutex_t run_mu;            /* one th_pool_run at a time */
+    pthread_mutex_t mu;
+    pthread_cond_t wake, done;
+    pthread_t th[TH_POOL_MAX];
+    int nworkers;                      /* threads created so far (the caller is an extra one) */
+    unsigned long gen;                 /* job generation */
+    int want;                          /* workers that take part in the current job */
+    int running;                       /* workers still inside the current job */
+    void (*fn)(void *, long);
+    void *arg;
+    long nchunks;
+    long next;                         /* next chunk to hand out (atomic) */
+} g_pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+             {0}, 0, 0, 0, 0, NULL, NULL, 0, 0 };
+
+static void pool_drain(void)
+{
+    for (;;) {
+        long c = __atomic_fetch_add(&g_pool.next, 1, __ATOMIC_RELAXED);
+        if (c >= g_pool.nchunks) break;
+        g_pool.fn(g_pool.arg, c);
+    }
+}
+
+static void *pool_worker(void *idp)
+{
+    const int id = (int)(size_t)idp;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.mu);
+    for (;;) {
+        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.wake, &g_pool.mu);
+        seen = g_pool.gen;
+        if (id >= g_pool.want) continue;            /* not part of this job */
+        pthread_mutex_unlock(&g_pool.mu);
+        pool_drain();
+        pthread_mutex_lock(&g_pool.mu);
+        if (--g_pool.running == 0) pthread_cond_signal(&g_pool.done);
+    }
+    return NULL;
+}
+
+void th_pool_run(int nthreads, void (*fn)(void *arg, long chunk), void *arg, long nchunks)
+{
+    if (nchunks <= 0) return;
+    if (nthreads > nchunks) nthreads = (int)nchunks;
+    if (nthreads > TH_POOL_MAX + 1) nthreads = TH_POOL_MAX + 1;
+    if (nthreads <= 1) {
+        for (long c = 0; c < nchunks; c++) fn(arg, c);
+        return;
+    }
+    pthread_mutex_lock(&g_pool.run_mu);
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.nworkers < nthreads - 1) {        /* grow the pool; workers are daemons for the life of the process */
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        if (pthread_create(&g_pool.th[g_pool.nworkers], &at, pool_worker, (void *)(size_t)g_pool.nworkers) != 0) {
+            pthread_attr_destroy(&at);
+            break;
+        }
+        pthread_attr_destroy(&at);
+        g_pool.nworkers++;
+    }
+    const int helpers = g_pool.nworkers < nthreads - 1 ? g_pool.nworkers : nthreads - 1;
+    g_pool.fn = fn; g_pool.arg = arg; g_pool.nchunks = nchunks;
+    __atomic_store_n(&g_pool.next, 0, __ATOMIC_RELAXED);
+    g_pool.want = helpers; g_pool.running = helpers;
+    g_pool.gen++;
+    pthread_cond_broadcast(&g_pool.wake);
+    pthread_mutex_unlock(&g_pool.mu);
+    pool_drain();                                   /* the caller works too */
+    pthread_mutex_lock(&g_pool.mu);
+    while (g_pool.running > 0) pthread_cond_wait(&g_pool.done, &g_pool.mu);
+    pthread_mutex_unlock(&g_pool.mu);
+    pthread_mutex_unlock(&g_pool.run_mu);
+}
+
+
+/* ------------------------------------------------------------------ */
 /* GAMMLN M:4598-4620 (6-term Lanczos; returns default REAL = fp64 in P64) */
 double th_oracle_gammln(double xx)
 {

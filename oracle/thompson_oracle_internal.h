@@ -134,6 +134,12 @@ struct th_oracle {
 void *th_oracle_make_view(const struct th_oracle *c);        /* P64 build of the column file */
 void *th_oracle_make_view_p32n(const struct th_oracle *c);   /* P32n build (thompson_oracle_p32n.c) */
 
+/* Persistent worker pool shared by both arithmetic builds (defined once, thompson_oracle_init.c).
+ * th_pool_run calls fn(arg, chunk) for every chunk in [0, nchunks) on `nthreads` threads (the caller is one of
+ * them); chunks are handed out dynamically.  Threads are created on first use and kept, so a timed region made of
+ * many batch calls pays no pthread_create/join per call.  Calls are serialised by a mutex. */
+void th_pool_run(int nthreads, void (*fn)(void *arg, long chunk), void *arg, long nchunks);
+
 /* column-major index helpers (1-based arguments) */
 #define IX2(i,j,n1)             ((size_t)((i)-1) + (size_t)(n1)*((j)-1))
 #define IX3(i,j,k,n1,n2)        ((size_t)((i)-1) + (size_t)(n1)*(((j)-1) + (size_t)(n2)*((k)-1)))

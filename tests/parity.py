@@ -137,7 +137,9 @@ def verdict(cmp, tol=TOL, sens_factor=10.0, sens_cut=1e-11):
       n_unmatched        levels (any kind) beyond max(tol, sens_factor * sens): these are failures
       n_branch_levels    levels on a residue-decided test
       n_sensitive        levels whose oracle output moves by more than sens_cut under ulp perturbations, and
-      worst_sensitive    the worst error / sensitivity ratio among them"""
+      worst_sensitive    the worst error / sensitivity ratio among them
+      max_err_any        worst error over ALL levels (nothing filtered), n_beyond_tol the number of levels beyond
+                         `tol`, cols_within_tol_frac the fraction of columns with every level within `tol`"""
     err, sens, flags = cmp["err"], cmp["sens"], cmp["flags"]
     steady = sens <= sens_cut
     lim = np.maximum(tol, sens_factor * sens)
@@ -146,7 +148,11 @@ def verdict(cmp, tol=TOL, sens_factor=10.0, sens_cut=1e-11):
                n_unmatched=int((err > lim).sum()), n_levels=int(err.size),
                n_branch_levels=int((flags != 0).sum()), n_sensitive=int((~steady).sum()),
                worst_sensitive=float(ratio.max()) if ratio.size else 0.0,
-               max_err_any=float(err.max()) if err.size else 0.0)
+               max_err_any=float(err.max()) if err.size else 0.0,
+               # the plain statistics against `tol`, no level left out and no allowance for sensitivity
+               n_beyond_tol=int((err > tol).sum()),
+               cols_within_tol_frac=float((err <= tol).all(axis=1).mean()) if err.ndim == 2 and err.size else 1.0,
+               max_sens=float(sens.max()) if sens.size else 0.0)
     if cmp.get("ppt_err") is not None:
         out["max_rel_ppt"] = float(cmp["ppt_err"].max())
         out["max_rel"] = max(out["max_rel"], out["max_rel_ppt"])
@@ -158,15 +164,25 @@ def branch_aware_max_rel(oracle, st, dt, got, got_ppt=None, tol=TOL):
     return verdict(branch_aware_compare(oracle, st, dt, got, got_ppt), tol=tol)
 
 
+ABS_CEILING = 1e-6          # no level may be further off than this, however sensitive the oracle is there
+MAX_SENSITIVE_FRAC = 0.02   # at most this share of the levels may lean on the sensitivity allowance
+
+
 def assert_parity(oracle, st, dt, got, got_ppt, tol=TOL, sens_factor=10.0, tol_ppt=None, depletion=0.0,
-                  max_branch_frac=None, min_cols_within=None, tol_cols=TOL):
+                  max_branch_frac=None, min_cols_within=None, tol_cols=TOL, ceiling=ABS_CEILING,
+                  max_sensitive_frac=MAX_SENSITIVE_FRAC):
     """The parity assertion of the -m gpu tests: EVERY level within max(tol, sens_factor x the oracle's own
     sensitivity there), levels on the reference's residue-decided tests against the better of their two admissible
-    outcomes; precipitation within tol_ppt.  Optionally: at most max_branch_frac of the levels on such tests, and
-    at least min_cols_within of the columns with every level within tol_cols.  Returns the verdict dict."""
+    outcomes; precipitation within tol_ppt.  The sensitivity allowance is itself bounded: no level beyond
+    max(tol, ceiling) whatever the oracle's sensitivity there, and at most max_sensitive_frac of the levels beyond
+    `tol` at all (i.e. passing only because of the allowance).  Optionally: at most max_branch_frac of the levels on
+    residue-decided tests, and at least min_cols_within of the columns with every level within tol_cols.
+    Returns the verdict dict."""
     cmp = branch_aware_compare(oracle, st, dt, got, got_ppt, depletion=depletion)
     v = verdict(cmp, tol=tol, sens_factor=sens_factor)
     assert v["n_unmatched"] == 0, v
+    assert v["max_err_any"] <= max(tol, ceiling), v
+    assert v["n_beyond_tol"] <= int(np.ceil(max_sensitive_frac * v["n_levels"])), v
     if got_ppt is not None:
         assert v["max_rel_ppt"] < (tol if tol_ppt is None else tol_ppt), v
     if max_branch_frac is not None:

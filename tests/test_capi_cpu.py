@@ -78,3 +78,50 @@ def test_fortran_shim_binds_the_c_abi():
     assert re.search(r"subroutine mp_thompson \(qv1d, qc1d, qi1d, qr1d, qs1d, qg1d, ni1d, &\s*"
                      r"nr1d, nc1d, nwfa1d, nifa1d, t1d, p1d, w1d, dzq, &\s*"
                      r"pptrain, pptsnow, pptgraul, pptice, &\s*kts, kte, dt, ii, jj\)", src)
+
+
+# ---- host-side pieces of the multi-GPU entry (no GPU needed) ----
+def test_shard_bounds_partition_the_columns():
+    """kidmp_shard_bounds: contiguous, exhaustive, sizes differ by at most one, identical to kid_amd.sharding's."""
+    from kid_amd import sharding, thompson
+    for ncol in (0, 1, 7, 8, 9, 1000, 10 ** 6, 10 ** 6 + 5):
+        for n in (1, 2, 3, 8):
+            b = [thompson.shard_bounds(ncol, n, i) for i in range(n)]
+            assert b[0][0] == 0 and b[-1][1] == ncol
+            assert all(b[i][1] == b[i + 1][0] for i in range(n - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+            assert b == [sharding.shard_bounds(ncol, i, n) for i in range(n)]
+    with pytest.raises(thompson.KidmpError):
+        thompson.shard_bounds(10, 2, 2)
+
+
+def test_exact_precipitation_limbs_convert_like_exact_rationals():
+    """kidmp_ppt_limbs_to_sums: limb j of a species weighs 2**(32 j - 128); un-normalised limbs (what an all-reduce
+    of many partial sums leaves: each up to 2**63) must give the same doubles as the exact rational sum."""
+    import random
+    from fractions import Fraction
+    import numpy as np
+    from kid_amd import thompson
+    rnd = random.Random(7)
+    for trial in range(200):
+        limbs, want = [], []
+        for sp in range(4):
+            total = 0
+            mine = []
+            for j in range(6):
+                v = rnd.randrange(-2 ** 62, 2 ** 62) if trial % 2 else rnd.randrange(0, 2 ** 32)
+                if j >= 4 and trial % 3 == 0:
+                    v = 0
+                mine.append(v)
+                total += v << (32 * j)
+            limbs += mine
+            want.append(float(Fraction(total, 2 ** 128)))
+        got = thompson.limbs_to_sums(np.array(limbs, dtype=np.int64))
+        for g, w in zip(got, want):
+            assert g == w or abs(g - w) <= abs(w) * 2.3e-16, (g, w)     # long-double summation: within one rounding
+    # and two different splittings of one total agree bit for bit
+    a = np.zeros(24, dtype=np.int64); b = np.zeros(24, dtype=np.int64)
+    a[0], a[1] = 2 ** 40 + 5, 7
+    b[0], b[1] = 5, 7 + 2 ** 8                                       # 2**40 = 2**8 * 2**32 carried into limb 1
+    assert np.array_equal(thompson.limbs_to_sums(a), thompson.limbs_to_sums(b))

@@ -43,6 +43,12 @@ def test_two_shards_equal_one_batch(name, iiwarm, ncol):
         dp = [p.diagnostics() for p in parts]
         # the reductions a multi-rank run all-reduces: SUM of the precipitation and rate sums, MAX / SUM of the scan
         np.testing.assert_allclose((dp[0]["precip"] + dp[1]["precip"]).cpu().numpy(), dw["precip"].cpu().numpy(), rtol=1e-13)
+        # the exchange itself is exact: the int64 accumulators of the shards add up to the unsharded ones bit for bit,
+        # hence so do the domain sums formed from them (what a multi-rank run all-reduces)
+        from kid_amd.thompson import limbs_to_sums
+        both = dp[0]["precip_limbs"] + dp[1]["precip_limbs"]
+        assert torch.equal(both, dw["precip_limbs"])
+        assert np.array_equal(limbs_to_sums(both.cpu().numpy()), dw["precip"].cpu().numpy())
         np.testing.assert_allclose((dp[0]["rates"] + dp[1]["rates"]).cpu().numpy(), dw["rates"].cpu().numpy(),
                                    rtol=1e-12, atol=1e-30)
         assert torch.equal(torch.maximum(dp[0]["sanity"][:7], dp[1]["sanity"][:7]), dw["sanity"][:7])

@@ -7,11 +7,12 @@ run a $2 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
 run b $2 "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT"
 run c $2 "FETCH_SIZE"
 run d $2 "WRITE_SIZE GRBM_GUI_ACTIVE"
+run e $2 "SQ_THREAD_CYCLES_VALU"
 python - <<PY
 import json
 out={}
-for x in "abcd":
-    d=json.load(open("gpurun_out/pmc_$2_%s.json"%x)); out.update(d["mean"]); out["meta"]=d["meta"]; out["dispatches"]=d["dispatches"]
+for x in "abcde":
+    d=json.load(open("gpurun_out/pmc_$2_%s.json"%x)); out.update(d["mean"]); out["meta"]=d["meta"] or out.get("meta"); out["dispatches"]=d["dispatches"]
 out["workload"]="$1"; out["ncol"]=int(out["meta"]["Grid_Size"])//64
 # the code object these counters were measured on (bench.py refuses the profile for any other build)
 import sys; sys.path.insert(0, ".")
