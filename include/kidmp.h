@@ -248,6 +248,13 @@ int64_t kidmp_get_const(kidmp_ctx *ctx, const char *name, double *out, int64_t c
  * `dir` is the directory holding the two files (the reference hard-codes "run_data"). */
 int kidmp_save_table_cache(kidmp_ctx *ctx, const char *dir);
 int kidmp_load_table_cache(kidmp_ctx *ctx, const char *dir);
+/* thompson_init's own use of the two files, as the reference does it per file (M:3717-3729 / M:3822-3829 for racg,
+ * M:3864-3895 / M:4065-4078 for racs): if the file exists AND l_reuse (KiD's switch l_reuse_thompson_lookup, M:20) its
+ * tables replace the GPU-built ones; otherwise the GPU-built tables are written to it (write_if_built = 0 skips that,
+ * e.g. on the second and later devices of a multi-GPU host).  *status (may be NULL): bit 0 / 1 = racg / racs read from
+ * file, bit 2 / 3 = racg / racs written.  A missing directory is not an error here (the reference aborts, M:3718):
+ * nothing is written.  No-op for an iiwarm context (M:773). */
+int kidmp_table_cache_reuse(kidmp_ctx *ctx, const char *dir, int32_t l_reuse, int32_t write_if_built, int32_t *status);
 /* The same format on host buffers (no GPU needed): ntab arrays of n_each doubles, Fortran element order. */
 int kidmp_cache_write_file(const char *path, int32_t ntab, const double *const *tabs, int64_t n_each);
 int kidmp_cache_read_file(const char *path, int32_t ntab, double *const *tabs, int64_t n_each);

@@ -5,6 +5,7 @@
 
 #include <rccl/rccl.h>              // types only: the library is dlopen'ed by kidmp_init_multi (a one-GPU host needs no RCCL)
 #include <dlfcn.h>
+#include <sys/stat.h>
 
 #include <chrono>
 #include <cstdio>
@@ -924,6 +925,53 @@ int kidmp_save_table_cache(kidmp_ctx *ctx, const char *dir)
         const std::string path = std::string(dir) + "/" + fam.file;
         if (cache_write(path.c_str(), int(ptr.size()), ptr.data(), fam.n) != 0) return fail(ctx, KIDMP_EIO, "cannot write " + path);
     }
+    return KIDMP_OK;
+}
+
+// thompson_init's use of the cache files, per file as in the reference: qr_acr_qg (M:3717-3729, M:3822-3829) and
+// qr_acr_qs (M:3864-3895, M:4065-4078) each do
+//     inquire(file=..., exist=fexist);  fexist = fexist .and. l_reuse_thompson_lookup
+//     if (fexist) then  read the 6 (12) tables  else  compute them and write(12,*) / write(13,*) them
+int kidmp_table_cache_reuse(kidmp_ctx *ctx, const char *dir, int32_t l_reuse, int32_t write_if_built, int32_t *status)
+{
+    if (status) *status = 0;
+    if (!ctx || !ctx->ready || !dir) return fail(ctx, KIDMP_ESTATE, "kidmp_table_cache_reuse: bad context");
+    if (ctx->hc.iiwarm) return KIDMP_OK;                     // thompson_init builds these tables only if .not. iiwarm (M:773)
+    GUARD(ctx);
+    struct stat sb;
+    const bool have_dir = stat(dir, &sb) == 0 && S_ISDIR(sb.st_mode);
+    bool loaded = false;
+    int fam_no = 0;
+    for (CacheFamily &fam : cache_families(ctx->tables)) {
+        const std::string path = std::string(dir) + "/" + fam.file;
+        bool fexist = false;
+        if (FILE *f = std::fopen(path.c_str(), "r")) { fexist = true; std::fclose(f); }
+        std::vector<std::vector<double>> host(fam.dev.size(), std::vector<double>(size_t(fam.n)));
+        if (fexist && l_reuse) {
+            std::vector<double *> ptr;
+            for (auto &h : host) ptr.push_back(h.data());
+            const int rc = cache_read(path.c_str(), int(ptr.size()), ptr.data(), fam.n);
+            if (rc != 0) return fail(ctx, KIDMP_EIO, (rc == -1 ? "cannot open " : "malformed or short table cache ") + path);
+            for (size_t i = 0; i < fam.dev.size(); ++i)
+                HIPTRY(ctx, hipMemcpy(fam.dev[i], host[i].data(), size_t(fam.n) * sizeof(double), hipMemcpyHostToDevice));
+            loaded = true;
+            if (status) *status |= 1 << fam_no;
+        } else if (write_if_built) {
+            // the reference opens the file unconditionally and aborts without the directory (M:3718); here a missing
+            // directory just means nothing is written (reported through *status)
+            if (have_dir) {
+                std::vector<const double *> ptr;
+                for (size_t i = 0; i < fam.dev.size(); ++i) {
+                    HIPTRY(ctx, hipMemcpy(host[i].data(), fam.dev[i], size_t(fam.n) * sizeof(double), hipMemcpyDeviceToHost));
+                    ptr.push_back(host[i].data());
+                }
+                if (cache_write(path.c_str(), int(ptr.size()), ptr.data(), fam.n) != 0) return fail(ctx, KIDMP_EIO, "cannot write " + path);
+                if (status) *status |= 4 << fam_no;
+            }
+        }
+        ++fam_no;
+    }
+    if (loaded) HIPTRY(ctx, repack_records(ctx->tables, ctx->stream));   // the solver reads the interleaved records
     return KIDMP_OK;
 }
 

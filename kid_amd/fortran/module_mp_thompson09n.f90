@@ -20,7 +20,16 @@
 !   'f32'   likewise, everything binary32.
 !
 ! Like the reference it takes its switches from KiD's own modules:
-! iiwarm, set_Nc (namelists, M:22), l_sediment (switches, M:20) and nx (parameters, M:23).
+! iiwarm, set_Nc (namelists, M:22), l_sediment and l_reuse_thompson_lookup (switches, M:20) and nx (parameters, M:23).
+! l_reuse_thompson_lookup keeps the reference's meaning (M:3717-3729, M:3864-3895): a run_data/racg_thompson09.data /
+! run_data/racs_thompson09.data that exists is READ when the switch is set; otherwise the tables are built (on the GPU)
+! and WRITTEN there, in the reference's list-directed format (without a run_data directory nothing is written; the
+! reference aborts in that case, M:3718).
+!
+! More than one GPU: kidmp_ndevices > 1 with kidmp_devices(1:kidmp_ndevices) (or the environment variable
+! KIDMP_DEVICES = "0,1,2,..."): thompson_init builds the tables on every device and mp_thompson_batch spreads the
+! columns over them in contiguous ranges (kidmp_batch_step_host_multi: one pipeline per device, the domain sums of the
+! surface precipitation reduced with RCCL and left in kidmp_precip_sums).  'p64' arithmetic only.
 !
 ! Side effects kept: the 36 process-rate diagnostics the reference emits from inside mp_thompson
 ! (M:2962-3124) are replayed after the batched call through KiD's own save_dg, same names, same
@@ -32,7 +41,7 @@
 module module_mp_thompson09n
 
   use iso_c_binding
-  use switches, only: l_sediment
+  use switches, only: l_sediment, l_reuse_thompson_lookup
   use namelists, only: iiwarm, set_Nc
   use parameters, only: nx
   use diagnostics, only: save_dg, i_dgtime
@@ -41,9 +50,16 @@ module module_mp_thompson09n
   private
 
   public :: thompson_init, mp_thompson, mp_thompson_batch, mp_thompson_staging, thompson_finalize
+  public :: kidmp_precip_sums_valid
   logical, public :: is_aerosol_aware = .false.          ! M:28 (read at thompson_init)
   logical, public :: l_rate_diagnostics = .true.         ! replay the save_dg calls of M:2962-3124
-  integer, public :: kidmp_device = 0                    ! HIP device ordinal of this process (one process per GPU)
+  integer, public :: kidmp_device = 0                    ! HIP device ordinal of this process (one GPU)
+  integer, public :: kidmp_ndevices = 1                  ! > 1: the columns are spread over kidmp_devices(1:kidmp_ndevices)
+  integer, public :: kidmp_devices(8) = (/ 0, 1, 2, 3, 4, 5, 6, 7 /)
+  ! domain sums (rain, snow, graupel, ice) of ppt after the last mp_thompson_batch call on several devices: the
+  ! numerators of the nx-means of W:248-303, reduced over the devices with RCCL inside the library
+  real(c_double), public :: kidmp_precip_sums(4) = 0.0_c_double
+  character(64), public :: kidmp_cache_dir = 'run_data'  ! where the reference keeps its table cache (M:3710, M:3857)
   character(4), public :: kidmp_arith = 'p64 '           ! 'p64', or with 4-byte default REAL 'p32n' / 'f32'
 
   ! the diagnosed rates in the reference's emission order (M:2967-3119): 30 mixed-phase, then 6 warm
@@ -62,7 +78,8 @@ module module_mp_thompson09n
      integer(c_int32_t) :: is_aerosol_aware
   end type kidmp_cfg
 
-  type(c_ptr), save :: ctx = c_null_ptr
+  type(c_ptr), save :: ctx = c_null_ptr                  ! the context (of the first device, when there are several)
+  type(c_ptr), save :: mctx = c_null_ptr                 ! kidmp_multi handle, when kidmp_ndevices > 1
   ! Staging arrays of mp_thompson_batch: page-locked (kidmp_host_alloc) and kept between calls, so that the library's
   ! upload / step / download pipeline can move them by DMA.  1 = state (12 profiles), 2 = p, w, dz, 3 = ppt,
   ! 4 = the 36 rate profiles, 5 = the substep counts.
@@ -95,6 +112,45 @@ module module_mp_thompson09n
        type(c_ptr), value :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt   ! real(c_double) [ncol][nz]; ppt [ncol][4]
        type(c_ptr), value :: rates, nstep            ! NULL, or [ncol][36][nz] doubles / [ncol][4] int32
      end function kidmp_batch_step_host_diag
+     integer(c_int) function kidmp_init_multi(cfg, ndev, devices, m_out) bind(C, name='kidmp_init_multi')
+       import :: c_int, c_int32_t, c_ptr, kidmp_cfg
+       type(kidmp_cfg), intent(in) :: cfg
+       integer(c_int32_t), value :: ndev
+       integer(c_int32_t), intent(in) :: devices(*)
+       type(c_ptr), intent(out) :: m_out
+     end function kidmp_init_multi
+     subroutine kidmp_finalize_multi(m) bind(C, name='kidmp_finalize_multi')
+       import :: c_ptr
+       type(c_ptr), value :: m
+     end subroutine kidmp_finalize_multi
+     type(c_ptr) function kidmp_multi_context(m, i) bind(C, name='kidmp_multi_context')
+       import :: c_ptr, c_int32_t
+       type(c_ptr), value :: m
+       integer(c_int32_t), value :: i
+     end function kidmp_multi_context
+     function kidmp_multi_last_error(m) result(msg) bind(C, name='kidmp_multi_last_error')
+       import :: c_ptr
+       type(c_ptr), value :: m
+       type(c_ptr) :: msg
+     end function kidmp_multi_last_error
+     integer(c_int) function kidmp_batch_step_host_multi(m, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, &
+          nc, nwfa, nifa, t, p, w, dz, ppt, rates, nstep, precip_sums) bind(C, name='kidmp_batch_step_host_multi')
+       import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: m
+       integer(c_int64_t), value :: ncol
+       integer(c_int32_t), value :: nz
+       real(c_double), value :: dt
+       type(c_ptr), value :: qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt, rates, nstep
+       real(c_double), intent(out) :: precip_sums(4)
+     end function kidmp_batch_step_host_multi
+     integer(c_int) function kidmp_table_cache_reuse(ctx, dir, l_reuse, write_if_built, status) &
+          bind(C, name='kidmp_table_cache_reuse')
+       import :: c_int, c_int32_t, c_ptr, c_char
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: dir(*)
+       integer(c_int32_t), value :: l_reuse, write_if_built
+       integer(c_int32_t), intent(out) :: status
+     end function kidmp_table_cache_reuse
      type(c_ptr) function kidmp_host_alloc(bytes) bind(C, name='kidmp_host_alloc')   ! page-locked host memory
        import :: c_ptr, c_size_t
        integer(c_size_t), value :: bytes
@@ -117,6 +173,11 @@ module module_mp_thompson09n
 
 contains
 
+  ! .true. when mp_thompson_batch ran on several devices and kidmp_precip_sums holds the RCCL-reduced domain sums
+  logical function kidmp_precip_sums_valid()
+    kidmp_precip_sums_valid = c_associated(mctx)
+  end function kidmp_precip_sums_valid
+
   subroutine stop_on_error(rc, where)
     integer(c_int), intent(in) :: rc
     character(*), intent(in) :: where
@@ -124,7 +185,11 @@ contains
     type(c_ptr) :: p
     integer :: n
     if (rc == 0) return
-    p = kidmp_last_error(ctx)
+    if (c_associated(mctx)) then
+       p = kidmp_multi_last_error(mctx)
+    else
+       p = kidmp_last_error(ctx)
+    end if
     write(*,'(a,a,a,i0)') ' module_mp_thompson09n: ', where, ' failed, kidmp code ', rc
     if (c_associated(p)) then
        call c_f_pointer(p, cmsg, [512])
@@ -151,22 +216,81 @@ contains
     end if
   end subroutine staging
 
-  ! thompson_init, M:374-797: constants on the host, lookup tables built on the GPU.
+  ! thompson_init, M:374-797: constants on the host, lookup tables built on the GPU (on every GPU of the device list).
   subroutine thompson_init
     type(kidmp_cfg) :: cfg
     integer(c_int) :: rc
-    character(16) :: envdev
-    integer :: envstat
+    integer(c_int32_t) :: devs(8), status, reuse, wr
+    type(c_ptr) :: c
+    character(64) :: envdev
+    character(kind=c_char) :: cdir(65)
+    integer :: envstat, i, n, pos, nxt
     if (c_associated(ctx)) return                         ! micro_init guard, M:384-389
     cfg%iiwarm = merge(1_c_int32_t, 0_c_int32_t, iiwarm)
     cfg%l_sediment = merge(1_c_int32_t, 0_c_int32_t, l_sediment)
     cfg%set_Nc = real(set_Nc, c_double)
     call get_environment_variable('KIDMP_DEVICE', envdev, status=envstat)
     if (envstat == 0 .and. len_trim(envdev) > 0) read(envdev, *, iostat=envstat) kidmp_device
+    call get_environment_variable('KIDMP_DEVICES', envdev, status=envstat)    ! "0,1,2,3": several GPUs
+    if (envstat == 0 .and. len_trim(envdev) > 0) then
+       n = 0;  pos = 1
+       do while (pos <= len_trim(envdev) .and. n < 8)
+          nxt = index(envdev(pos:), ',')
+          if (nxt == 0) nxt = len_trim(envdev) - pos + 2
+          n = n + 1
+          read(envdev(pos:pos+nxt-2), *, iostat=envstat) kidmp_devices(n)
+          if (envstat /= 0) then
+             write(*,'(2a)') ' module_mp_thompson09n: cannot read KIDMP_DEVICES=', trim(envdev)
+             stop 1
+          end if
+          pos = pos + nxt
+       end do
+       kidmp_ndevices = n
+    end if
     cfg%device = int(kidmp_device, c_int32_t)
     cfg%is_aerosol_aware = merge(1_c_int32_t, 0_c_int32_t, is_aerosol_aware)
-    rc = kidmp_init(cfg, ctx)
-    call stop_on_error(rc, 'thompson_init')
+    if (kidmp_ndevices > 1) then
+       if (kidmp_ndevices > 8) then
+          write(*,'(a)') ' module_mp_thompson09n: at most 8 devices'
+          stop 1
+       end if
+       if (trim(kidmp_arith) /= 'p64') then
+          write(*,'(a)') ' module_mp_thompson09n: several devices need kidmp_arith = p64'
+          stop 1
+       end if
+       devs(1:kidmp_ndevices) = int(kidmp_devices(1:kidmp_ndevices), c_int32_t)
+       rc = kidmp_init_multi(cfg, int(kidmp_ndevices, c_int32_t), devs, mctx)
+       call stop_on_error(rc, 'thompson_init (kidmp_init_multi)')
+       ctx = kidmp_multi_context(mctx, 0_c_int32_t)
+    else
+       rc = kidmp_init(cfg, ctx)
+       call stop_on_error(rc, 'thompson_init')
+    end if
+    ! ---- the reference's table cache, M:3717-3729 / M:3822-3829 and M:3864-3895 / M:4065-4078: per file, read it if
+    !      it exists and l_reuse_thompson_lookup is set, else write the freshly built tables (first device only) ----
+    if (.not. iiwarm) then
+       n = len_trim(kidmp_cache_dir)
+       do i = 1, n
+          cdir(i) = kidmp_cache_dir(i:i)
+       end do
+       cdir(n+1) = c_null_char
+       reuse = merge(1_c_int32_t, 0_c_int32_t, l_reuse_thompson_lookup)
+       do i = 1, max(1, kidmp_ndevices)
+          c = ctx
+          if (c_associated(mctx)) c = kidmp_multi_context(mctx, int(i-1, c_int32_t))
+          wr = merge(1_c_int32_t, 0_c_int32_t, i == 1)
+          rc = kidmp_table_cache_reuse(c, cdir, reuse, wr, status)
+          call stop_on_error(rc, 'thompson_init (table cache)')
+          if (i == 1 .and. iand(status, 3_c_int32_t) /= 0) then          ! the reference's notice, M:3872-3881
+             write(6,*) ' !!!!!!!!!!!!!!!!!! WARNING !!!!!!!!!!!!!!!!!!!'
+             write(6,*) ' Reading in pre-calculated lookup tables in    '
+             write(6,*) ' Thompson scheme'
+             write(6,*) ' If you have changed any microphysical '
+             write(6,*) ' parameters, you may need to recalculate these. '
+             write(6,*) ' !!!!!!!!!!!!!!!!!! WARNING !!!!!!!!!!!!!!!!!!!'
+          end if
+       end do
+    end if
   end subroutine thompson_init
 
   subroutine thompson_finalize
@@ -175,8 +299,12 @@ contains
        if (c_associated(hbuf(i))) call kidmp_host_free(hbuf(i))
        hbuf(i) = c_null_ptr;  hbytes(i) = 0_c_size_t
     end do
-    if (c_associated(ctx)) call kidmp_finalize(ctx)
-    ctx = c_null_ptr
+    if (c_associated(mctx)) then
+       call kidmp_finalize_multi(mctx)                    ! finalises every context, ctx among them
+    else if (c_associated(ctx)) then
+       call kidmp_finalize(ctx)
+    end if
+    ctx = c_null_ptr;  mctx = c_null_ptr
   end subroutine thompson_finalize
 
   ! mp_thompson, M:1156-1177: one column, reference dummy list.
@@ -347,9 +475,15 @@ contains
        ps(3) = c_null_ptr;  ps(5) = c_null_ptr;  ps(6) = c_null_ptr;  ps(7) = c_null_ptr
     end if
     if (.not. have_aer) ps(9:11) = c_null_ptr
-    rc = kidmp_batch_step_host_diag(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_double), &
-         ps(1), ps(2), ps(3), ps(4), ps(5), ps(6), ps(7), ps(8), ps(9), ps(10), ps(11), ps(12), &
-         pf(1), pf(2), pf(3), c_loc(pp), prates, pnstep)
+    if (c_associated(mctx)) then                           ! several GPUs: contiguous column ranges, one pipeline each
+       rc = kidmp_batch_step_host_multi(mctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_double), &
+            ps(1), ps(2), ps(3), ps(4), ps(5), ps(6), ps(7), ps(8), ps(9), ps(10), ps(11), ps(12), &
+            pf(1), pf(2), pf(3), c_loc(pp), prates, pnstep, kidmp_precip_sums)
+    else
+       rc = kidmp_batch_step_host_diag(ctx, int(ncol, c_int64_t), int(nz, c_int32_t), real(dt, c_double), &
+            ps(1), ps(2), ps(3), ps(4), ps(5), ps(6), ps(7), ps(8), ps(9), ps(10), ps(11), ps(12), &
+            pf(1), pf(2), pf(3), c_loc(pp), prates, pnstep)
+    end if
     call stop_on_error(rc, 'mp_thompson')
     if (.not. inplace) then
     qv = s(:,:,1);  qc = s(:,:,2);  qr = s(:,:,4);  nr = s(:,:,8);  t = s(:,:,12)

@@ -78,16 +78,17 @@ contains
     if (.not. allocated(total)) allocate(total(nx))
 
     ! ---- gather: state + (advective + divergence forcing)*dt, W:59-97 ----
+    ! Columns are independent: the loop over i is shared among OpenMP threads when the model is built with OpenMP
+    ! (the directives are comments otherwise).  At nx = 10^4 this host-side packing, not the GPU, bounds a KiD step.
+    !$omp parallel do default(shared) private(i, k, m, s) schedule(static) if(nx >= 256)
     do i = 1, nx
        st(:,i,S_T)  = (theta(:,i) + (dtheta_adv(:,i) + dtheta_div(:,i))*dt)*exner(:,i)
        fo(:,i,1)    = p0*exner(:,i)**(1./r_on_cp)
        fo(:,i,3)    = dz(:)
        st(:,i,S_QV) = qv(:,i) + (dqv_adv(:,i) + dqv_div(:,i))*dt
-    end do
-    do m = 1, NHYD
-       if (iiwarm .and. hyd_spec(m) > 2) cycle
-       s = hyd_slot(m)
-       do i = 1, nx
+       do m = 1, NHYD
+          if (iiwarm .and. hyd_spec(m) > 2) cycle
+          s = hyd_slot(m)
           do k = 1, nz
              st(k,i,s) = hydrometeors(k,i,hyd_spec(m))%moments(1,hyd_mom(m)) &
                   + (dhydrometeors_adv(k,i,hyd_spec(m))%moments(1,hyd_mom(m)) &
@@ -95,11 +96,17 @@ contains
           end do
        end do
     end do
+    !$omp end parallel do
     ! What the reference leaves unset (nc1d, nwfa1d, nifa1d, w1d; W:36): with is_aerosol_aware they are read, and get
     ! the scheme's non-aerosol defaults (M:958-964) and no updraft here; without it they are left out of the call and
     ! the library forms the same defaults on the GPU, so they never cross PCIe.
     if (is_aerosol_aware) then
        fo(:,:,2) = 0.0
+       if (iiwarm) then
+          ! a warm run keeps qc1d..qg1d at their initial zeros (W:46-52): the aerosol-aware call below passes all
+          ! twelve slots, and the staging memory is neither zeroed by the library nor by ALLOCATE
+          st(:,:,S_QI) = 0.0;  st(:,:,S_QS) = 0.0;  st(:,:,S_QG) = 0.0;  st(:,:,S_NI) = 0.0
+       end if
        do i = 1, nx
           do k = 1, nz
              rho = 0.622*fo(k,i,1)/(287.04*st(k,i,S_T)*(st(k,i,S_QV)+0.622))
@@ -125,14 +132,13 @@ contains
     end if
 
     ! ---- back out the microphysics tendencies, W:198-245 ----
+    !$omp parallel do default(shared) private(i, k, m, s) schedule(static) if(nx >= 256)
     do i = 1, nx
        dtheta_mphys(:,i) = (st(:,i,S_T)/exner(:,i) - theta(:,i))/dt - (dtheta_adv(:,i) + dtheta_div(:,i))
        dqv_mphys(:,i)    = (st(:,i,S_QV) - qv(:,i))/dt - (dqv_adv(:,i) + dqv_div(:,i))
-    end do
-    do m = 1, NHYD
-       if (iiwarm .and. hyd_spec(m) > 2) cycle
-       s = hyd_slot(m)
-       do i = 1, nx
+       do m = 1, NHYD
+          if (iiwarm .and. hyd_spec(m) > 2) cycle
+          s = hyd_slot(m)
           do k = 1, nz
              dhydrometeors_mphys(k,i,hyd_spec(m))%moments(1,hyd_mom(m)) = &
                   (st(k,i,s) - hydrometeors(k,i,hyd_spec(m))%moments(1,hyd_mom(m)))/dt &
@@ -141,6 +147,7 @@ contains
           end do
        end do
     end do
+    !$omp end parallel do
 
     ! ---- surface precipitation diagnostics ----
     imom = 1

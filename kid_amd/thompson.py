@@ -123,6 +123,8 @@ def load_library(path=None):
     L.kidmp_save_table_cache.argtypes = [_vp, C.c_char_p]
     L.kidmp_load_table_cache.restype = C.c_int
     L.kidmp_load_table_cache.argtypes = [_vp, C.c_char_p]
+    L.kidmp_table_cache_reuse.restype = C.c_int
+    L.kidmp_table_cache_reuse.argtypes = [_vp, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.kidmp_cache_write_file.restype = C.c_int
     L.kidmp_cache_write_file.argtypes = [C.c_char_p, C.c_int32, C.POINTER(_dp), C.c_int64]
     L.kidmp_cache_read_file.restype = C.c_int
@@ -433,6 +435,14 @@ class ThompsonMP:
 
     def load_table_cache(self, directory):
         self._check(load_library().kidmp_load_table_cache(self._h, os.fsencode(directory)))
+
+    def table_cache_reuse(self, directory, l_reuse, write_if_built=True):
+        """thompson_init's use of run_data/*.data (M:3717-3729, M:3864-3895): read a file that exists when l_reuse,
+        else write the GPU-built tables.  Returns the status bits (1, 2: racg, racs read; 4, 8: written)."""
+        st = C.c_int32(0)
+        self._check(load_library().kidmp_table_cache_reuse(self._h, os.fsencode(directory), int(bool(l_reuse)),
+                                                           int(bool(write_if_built)), C.byref(st)))
+        return st.value
 
     @staticmethod
     def kernel_name():

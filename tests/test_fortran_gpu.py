@@ -206,3 +206,129 @@ def test_native_real4_kid_build_in_the_reference_native_arithmetic():
     # the 8-byte build refuses the binary32 arithmetic instead of converting silently
     out = subprocess.run([EXE, "1", "2", "warm", "0", "p32n"], capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and "4-byte default REAL" in out.stdout + out.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The adapter's forcing path (W:59-97 forms state + (adv + div)*dt, W:198-245 subtracts adv + div again), the warm
+# aerosol-aware call, the reference's table-cache switch and the multi-device entry, all through the Fortran drop-in.
+_ENV = dict(os.environ, OMP_NUM_THREADS="8")
+_HYD = ((0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (3, 0), (4, 0))     # (KiD species - 1, moment - 1) in dump order
+
+
+def _run_opts(tmp_path, nx, nsteps, case, *opts, dump_step=0):
+    out = subprocess.run([EXE, str(nx), str(nsteps), case, str(dump_step), "p64", "-"] + list(opts), capture_output=True,
+                         text=True, timeout=900, cwd=str(tmp_path), env=_ENV)
+    assert out.returncode == 0, out.stdout + out.stderr
+    vals = {}
+    for line in out.stdout.splitlines():
+        p = line.split()
+        if p and p[0] in ("KATB", "KATBN", "PSUM", "TIME"):
+            vals[p[0]] = np.array([float(x) for x in p[1:]])
+    return vals, out.stdout
+
+
+def _oracle_adapter(oracle, d, nx, nz=120, dt=10.0):
+    """oracle.kid_interface on the dumped inputs; returns (dtheta, dqv, dhyd[7]) as [nx, nz] arrays."""
+    def f(a):                                                         # [nx, nz] -> Fortran (nz, nx) flattened
+        return np.ascontiguousarray(a).ravel()
+    hy, ha, hd = (np.zeros((2, 5, nx, nz)) for _ in range(3))         # hydro[k + nz*(i + nx*(ih + 5*imom))]
+    for n, (ih, im) in enumerate(_HYD):
+        hy[im, ih], ha[im, ih], hd[im, ih] = d[:, :, 4 + n], d[:, :, 15 + n], d[:, :, 22 + n]
+    dth, dqv, dhy, _ = oracle.kid_interface(nz, nx, dt, 1.0e5, 287.058 / 1005.0, f(d[:, :, 0]), f(d[:, :, 11]), f(d[:, :, 12]),
+                                            f(d[:, :, 1]), d[0, :, 3].copy(), f(d[:, :, 2]), f(d[:, :, 13]), f(d[:, :, 14]),
+                                            hy.ravel(), ha.ravel(), hd.ravel())
+    dhy = dhy.reshape(2, 5, nx, nz)
+    return dth.reshape(nx, nz), dqv.reshape(nx, nz), [dhy[im, ih] for ih, im in _HYD]
+
+
+def _check_mphys(d, ref, nx, what):
+    dth, dqv, dhy = ref
+    got = [d[:, :, 29], d[:, :, 30]] + [d[:, :, 31 + n] for n in range(7)]
+    want = [dth, dqv] + dhy
+    # tendencies are differences of O(1) states divided by dt: measure against the size of the state's own rate
+    scale = [np.abs(d[:, :, 0]).max() / 10.0, np.abs(d[:, :, 2]).max() / 10.0] + [max(np.abs(d[:, :, 4 + n]).max() / 10.0, 1e-300) for n in range(7)]
+    for n, (g, w, sc) in enumerate(zip(got, want, scale)):
+        err = np.abs(g - w) / np.maximum(np.abs(w), 1e-5 * sc)      # floor: a few ulp of state / dt
+        assert err.max() < 1e-9, (what, n, float(err.max()))
+    return got, want
+
+
+@pytest.mark.parametrize("case", ["warm", "mixed"])
+def test_adapter_forcing_terms_match_oracle(tmp_path, oracle_warm, oracle_mixed, case):
+    """A prescribed updraft + divergence forcing (non-zero dtheta_adv/div, dqv_adv/div, dhydrometeors_adv/div): the
+    drop-in's d*_mphys equal the oracle adapter's (W:59-97, W:198-245) at 1e-9, and the forcing really acts."""
+    nx = 3
+    _run_opts(tmp_path, nx, 6, case, "forcing=1", "mphys=5")
+    d = np.loadtxt(os.path.join(str(tmp_path), "mphys_dump.txt")).reshape(nx, 120, 38)
+    assert np.abs(d[:, :, 11]).max() > 1e-4 and np.abs(d[:, :, 13]).max() > 1e-8 and np.abs(d[:, :, 15:29]).max() > 1e-9
+    oracle = oracle_warm if case == "warm" else oracle_mixed
+    got, want = _check_mphys(d, _oracle_adapter(oracle, d, nx), nx, case)
+    # with the forcing terms dropped from the oracle's input the tendencies differ visibly: the terms are not inert
+    d0 = d.copy()
+    d0[:, :, 11:29] = 0.0
+    dth0, _, _ = _oracle_adapter(oracle, d0, nx)
+    assert np.abs(dth0 - want[0]).max() > 1e-6
+
+
+def test_warm_aerosol_aware_run_through_the_drop_in(tmp_path):
+    """iiwarm with is_aerosol_aware: the adapter passes all twelve state slots, the four frozen ones zeroed (W:46-52);
+    d*_mphys equal the oracle adapter's with the same switches."""
+    from oracle.oracle import Oracle
+    nx = 2
+    _run_opts(tmp_path, nx, 5, "warm", "aero=1", "mphys=5")
+    d = np.loadtxt(os.path.join(str(tmp_path), "mphys_dump.txt")).reshape(nx, 120, 38)
+    o = Oracle(iiwarm=True, aerosol_aware=True)
+    try:
+        _check_mphys(d, _oracle_adapter(o, d, nx), nx, "warm aerosol-aware")
+    finally:
+        o.close()
+    assert np.all(d[:, :, 34:38] == 0.0)                               # no frozen-species tendency out of a warm run
+
+
+def test_l_reuse_thompson_lookup_semantics(tmp_path, gpu_mixed):
+    """The reference's cache switch (M:3717-3729, M:3864-3895) in the drop-in: with the switch set a file that exists is
+    READ (here: tables of zeros, so collection of rain by snow / graupel vanishes and the run ends elsewhere); with the
+    switch off the same files are ignored and OVERWRITTEN by the freshly built tables; a later run with the switch set
+    then reproduces the computed-table run bit for bit (17 significant digits round-trip binary64)."""
+    from kid_amd import cache_read_file, cache_write_file
+    rd = tmp_path / "run_data"
+    rd.mkdir()
+    plain = tmp_path / "plain"
+    plain.mkdir()
+    base, _ = _run_opts(plain, 2, 3, "mixed")                          # no run_data beside this run: nothing read or written
+    assert not list(plain.glob("run_data*"))
+    n_racg, n_racs = 37 * 37 * 28 * 28, 28 * 9 * 37 * 37
+    cache_write_file(str(rd / "racg_thompson09.data"), [np.zeros(n_racg)] * 6)
+    cache_write_file(str(rd / "racs_thompson09.data"), [np.zeros(n_racs)] * 12)
+    zeroed, out = _run_opts(tmp_path, 2, 3, "mixed", "reuse=1")
+    assert "Reading in pre-calculated lookup tables" in out
+    assert not np.array_equal(zeroed["KATB"], base["KATB"])           # the perturbed tables were picked up
+    ignored, out = _run_opts(tmp_path, 2, 3, "mixed", "reuse=0")
+    assert "Reading in pre-calculated" not in out
+    assert np.array_equal(ignored["KATB"], base["KATB"]) and np.array_equal(ignored["KATBN"], base["KATBN"])
+    got = cache_read_file(str(rd / "racg_thompson09.data"), 6, n_racg)   # ... and replaced by the built tables
+    for name, g in zip(("tcg_racg", "tmr_racg", "tcr_gacr", "tmg_gacr", "tnr_racg", "tnr_gacr"), got):
+        assert np.array_equal(g, gpu_mixed.table(name)), name
+    again, out = _run_opts(tmp_path, 2, 3, "mixed", "reuse=1")
+    assert "Reading in pre-calculated lookup tables" in out
+    assert np.array_equal(again["KATB"], base["KATB"]) and np.array_equal(again["KATBN"], base["KATBN"])
+
+
+def test_two_devices_through_the_drop_in(tmp_path):
+    """kidmp_devices = (0, 0): the columns are spread over two contexts by kidmp_batch_step_host_multi; end state
+    bitwise as on one device, and the RCCL-reduced domain sums equal the sum of the per-column precipitation the adapter
+    hands to save_dg (W:283-303)."""
+    nx = 7
+    one, _ = _run_opts(tmp_path, nx, 60, "warm")
+    two, _ = _run_opts(tmp_path, nx, 60, "warm", "devices=0,0", dump_step=60)
+    assert np.array_equal(one["KATB"], two["KATB"]) and np.array_equal(one["KATBN"], two["KATBN"])
+    assert "PSUM" in two and "PSUM" not in one
+    per_col = {}
+    for line in open(os.path.join(str(tmp_path), "dg_dump.txt")):
+        p = line.split()
+        if p[0] == "array":
+            per_col.setdefault(p[1], []).append(float(p[4]))
+    rain = np.array(per_col["surface_ppt_for_rain"][nx:])             # second block: the per-column values
+    assert rain.sum() > 0
+    np.testing.assert_allclose(two["PSUM"][0], rain.sum(), rtol=1e-13)
+    assert np.all(two["PSUM"][1:] == 0.0)
