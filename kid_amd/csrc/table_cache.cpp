@@ -84,6 +84,7 @@ int cache_read(const char *path, int ntab, double *const *tabs, int64_t n_each)
         errno = 0;
         const double v = val.empty() ? 0.0 : std::strtod(val.c_str(), &e);            // "r*" = r nulls
         if (!val.empty() && (e == val.c_str() || *e != '\0')) return -3;
+        if (rep > total - got) rep = long(total - got);                               // a huge repeat count must not spin
         for (long r = 0; r < rep; ++r) put(v);
     }
     return got >= total ? 0 : -3;

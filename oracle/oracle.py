@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libthompson_oracle.so")
+# KIDMP_ORACLE_LIB: another build of the same checker (the sanitizer build oracle/_asan/..., tests/test_sanitizers.py)
+_LIB = os.environ.get("KIDMP_ORACLE_LIB") or os.path.join(_HERE, "libthompson_oracle.so")
 _CACHE_DIR = os.path.join(_HERE, "_cache")
 NRATES = 36
 RATE_NAMES = (
