@@ -60,6 +60,13 @@ def load_library(path=None):
             raise KidmpError("load_library: %s is already loaded" % _lib._name)
         return _lib
     path = os.path.abspath(path) if path else lib_path()
+    # torch ships its own HIP runtime: when this process is going to use torch (the device entries of this mirror
+    # take torch tensors) it must be loaded FIRST, so that libkidmp.so binds to the same libamdhip64 -- two HIP
+    # runtimes in one process leave the second one without a device ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(path):
         raise KidmpError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
