@@ -1,26 +1,38 @@
 #!/bin/bash
-# Regenerates everything under profiles/ for one round tag (run on the GPU box; results land in gpurun_out/):
-#   tools/refresh_profiles.sh r01
+# Regenerates everything under profiles/ for one round tag (run on the GPU box; results land in gpurun_out/profiles_<tag>):
+#   tools/refresh_profiles.sh r03
 set -e
 export TMPDIR=/tmp
-tag=${1:-r01}
+tag=${1:-r03}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
-for w in config2 config3 config5; do
+for w in config3 config5 config2; do
   bash tools/pmc_profile.sh $w ${tag}_$w > /dev/null
   cp gpurun_out/pmc_${tag}_$w.json $out/${tag}_pmc_$w.json
   echo "pmc $w done"
 done
-# the bench reads profiles/<tag>_pmc_<workload>.json for the measured HBM traffic
+# the bench reads profiles/<tag>_pmc_<workload>.json for the measured HBM traffic / VALU counts (fingerprint-checked)
 mkdir -p profiles && cp $out/${tag}_pmc_*.json profiles/
-for w in config2 config3 config5; do
-  python bench.py --no-other-workloads --workload $w > $out/${tag}_bench_$w.json
-  echo "bench $w: $(cut -c1-200 $out/${tag}_bench_$w.json)"
-done
-# rocprofv3 --kernel-trace --stats of the bench command itself, per workload (program directly after `--`)
-for w in config2 config3 config5; do
+python bench.py > $out/${tag}_bench_default.json
+echo "bench default: $(cut -c1-160 $out/${tag}_bench_default.json)"
+# rocprofv3 --kernel-trace --stats of the default bench command itself (program directly after `--`), plus the
+# average over the K timed launches only (rocprofv3's own average includes the W warm-up launches)
+for w in default config3 config5 config2; do
   rm -rf gpurun_out/prof_${tag}_$w
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$w -- python3 bench.py --no-other-workloads --no-cpu-baseline --workload $w > /dev/null 2>&1
+  if [ $w = default ]; then
+    # exactly `python bench.py`: three workloads in one process; the headline's 5 warm-up + 20 timed launches come first
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$w -- python3 bench.py > /dev/null 2>&1
+    python tools/kernel_stats_timed.py gpurun_out/prof_${tag}_$w 20 "ILi2ELi120ELi4ELb0ELb0ELb0" 5 > $out/${tag}_${w}_kernel_timed_launches.json
+  else
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$w -- python3 bench.py --no-cpu-baseline --no-other-workloads --workload $w > /dev/null 2>&1
+    python tools/kernel_stats_timed.py gpurun_out/prof_${tag}_$w 20 > $out/${tag}_${w}_kernel_timed_launches.json
+  fi
   cp $(ls -t gpurun_out/prof_${tag}_$w/*/*kernel_stats.csv | head -1) $out/${tag}_${w}_kernel_stats.csv
-  head -3 $out/${tag}_${w}_kernel_stats.csv
+  head -2 $out/${tag}_${w}_kernel_stats.csv | cut -c1-200
+  cat $out/${tag}_${w}_kernel_timed_launches.json | tr -d '\n' | cut -c1-300; echo
 done
+# per-pass: cumulative times, VALU / SALU instructions and lane utilisation (profiling build of the library)
+bash tools/pass_times.sh config3 config5 config2 > $out/${tag}_pass_times.txt
+bash tools/lane_util.sh config3 config5 config2 > $out/${tag}_lane_util_per_pass.txt
+bash tools/ncol_sweep.sh > $out/${tag}_ncol_sweep.txt
+cat $out/${tag}_pass_times.txt $out/${tag}_lane_util_per_pass.txt $out/${tag}_ncol_sweep.txt
