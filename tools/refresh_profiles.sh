@@ -22,7 +22,7 @@ for w in default config3 config5 config2; do
   if [ $w = default ]; then
     # exactly `python bench.py`: three workloads in one process; the headline's 5 warm-up + 20 timed launches come first
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$w -- python3 bench.py > /dev/null 2>&1
-    python tools/kernel_stats_timed.py gpurun_out/prof_${tag}_$w 20 "ILi2ELi120ELi4ELb0ELb0ELb0" 5 > $out/${tag}_${w}_kernel_timed_launches.json
+    python tools/kernel_stats_timed.py gpurun_out/prof_${tag}_$w 20 "thompson_column_step<2, 120, 4, false, false, false>" 5 > $out/${tag}_${w}_kernel_timed_launches.json
   else
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$w -- python3 bench.py --no-cpu-baseline --no-other-workloads --workload $w > /dev/null 2>&1
     python tools/kernel_stats_timed.py gpurun_out/prof_${tag}_$w 20 > $out/${tag}_${w}_kernel_timed_launches.json
