@@ -1,7 +1,8 @@
 /* The C ABI from plain C (c99): what INTEGRATION.md promises a C host.  Builds a few warm-rain columns, steps them
  * through kidmp_batch_step_host with the arrays KiD never fills left out, and writes its inputs (capi_in.bin: qv qc qr
  * nr t p dz) and results (capi_out.bin: qv qc qr nr t, then ppt) as raw doubles.  tests/test_gpu_capi_c.py steps the
- * same inputs through the Python wrapper and compares bit for bit. */
+ * same inputs through the Python wrapper and compares bit for bit.  With a device list as third argument the columns are
+ * then stepped again through the library's multi-device entry and compared with the single-device run. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,6 +61,39 @@ int main(int argc, char **argv)
         FILE *f = fopen("capi_out.bin", "wb");
         if (!f || fwrite(buf, sizeof(double), 5 * n, f) != 5 * n || fwrite(ppt, sizeof(double), 4 * (size_t)ncol, f) != 4 * (size_t)ncol) return 7;
         fclose(f);
+    }
+    /* the same columns once more from their initial state, spread over a device list by the library itself
+     * (kidmp_init_multi / kidmp_batch_step_host_multi: what a single-process C or Fortran host uses for several GPUs).
+     * argv[3] = the list, e.g. "0,0" (two contexts on one card) or "0,1,2,3"; results must equal the run above. */
+    if (argc > 3) {
+        int32_t devs[8];
+        int32_t ndev = 0;
+        const char *q = argv[3];
+        double *buf2 = (double *)kidmp_host_alloc(7 * n * sizeof(double));
+        double *ppt2 = (double *)kidmp_host_alloc(4 * (size_t)ncol * sizeof(double));
+        double sums[4] = {-1., -1., -1., -1.}, direct = 0.;
+        kidmp_multi *m = NULL;
+        size_t i, differ = 0;
+        FILE *f = fopen("capi_in.bin", "rb");
+        if (!buf2 || !ppt2 || !f || fread(buf2, sizeof(double), 7 * n, f) != 7 * n) return 8;
+        fclose(f);
+        while (*q && ndev < 8) { devs[ndev++] = (int32_t)strtol(q, (char **)&q, 10); if (*q == ',') ++q; }
+        for (c = 0; c < 4 * ncol; ++c) ppt2[c] = 0.0;
+        rc = kidmp_init_multi(&cfg, ndev, devs, &m);
+        if (rc) { fprintf(stderr, "kidmp_init_multi: %d %s\n", rc, kidmp_last_error(NULL)); return 9; }
+        for (s = 0; s < nsteps; ++s) {
+            rc = kidmp_batch_step_host_multi(m, ncol, nz, 10.0, buf2, buf2 + n, NULL, buf2 + 2 * n, NULL, NULL, NULL, buf2 + 3 * n,
+                                             NULL, NULL, NULL, buf2 + 4 * n, buf2 + 5 * n, NULL, buf2 + 6 * n, ppt2, NULL, NULL, sums);
+            if (rc) { fprintf(stderr, "kidmp_batch_step_host_multi: %d %s\n", rc, kidmp_multi_last_error(m)); return 10; }
+        }
+        for (i = 0; i < 5 * n; ++i) differ += buf2[i] != buf[i];
+        for (i = 0; i < 4 * (size_t)ncol; ++i) differ += ppt2[i] != ppt[i];
+        for (c = 0; c < ncol; ++c) direct += ppt2[4 * c];
+        printf("MULTI %d %lu %.17g %.17g %.17g %.17g %.17g\n", (int)kidmp_multi_size(m), (unsigned long)differ, sums[0], sums[1],
+               sums[2], sums[3], direct);
+        kidmp_finalize_multi(m);
+        kidmp_host_free(buf2);
+        kidmp_host_free(ppt2);
     }
     /* a mixed-phase context refuses the lean call instead of reading address 0 */
     kidmp_finalize(ctx);

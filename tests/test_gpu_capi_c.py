@@ -18,15 +18,21 @@ def test_c_program_equals_python_wrapper(tmp_path, gpu_warm):
                         "-Wl,-rpath," + lib], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ncol, nsteps, nz = 2500, 3, 120                          # two pipeline chunks... of a batch the C side fills
-    out = subprocess.run([exe, str(ncol), str(nsteps)], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    out = subprocess.run([exe, str(ncol), str(nsteps), "0,0"], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr
-    got = refused = None
+    got = refused = multi = None
     for line in out.stdout.splitlines():
         if line.startswith("CAPI"):
             got = np.array([float(x) for x in line.split()[1:]])
         if line.startswith("REFUSED"):
             refused = line
-    assert got is not None and refused is not None, out.stdout
+        if line.startswith("MULTI"):
+            multi = line.split()[1:]
+    assert got is not None and refused is not None and multi is not None, out.stdout
+    # the C host's multi-device leg (device list 0,0): two contexts, no element differs from the single-device run,
+    # the RCCL-reduced rain sum equals the sum of the per-column values, nothing but rain reaches the ground
+    assert int(multi[0]) == 2 and int(multi[1]) == 0, multi
+    assert abs(float(multi[2]) - float(multi[6])) <= 1e-13 * abs(float(multi[6])) and [float(x) for x in multi[3:6]] == [0.0, 0.0, 0.0]
     assert int(refused.split()[1]) < 0 and "mixed-phase context needs" in refused
 
     n = ncol * nz
