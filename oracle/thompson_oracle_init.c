@@ -60,9 +60,22 @@ static void *pool_worker(void *idp)
     return NULL;
 }
 
+/* a forked child inherits the pool's bookkeeping but none of its threads: start over there */
+static void pool_reset_in_child(void)
+{
+    pthread_mutex_init(&g_pool.run_mu, NULL);
+    pthread_mutex_init(&g_pool.mu, NULL);
+    pthread_cond_init(&g_pool.wake, NULL);
+    pthread_cond_init(&g_pool.done, NULL);
+    g_pool.nworkers = 0; g_pool.gen = 0; g_pool.want = 0; g_pool.running = 0;
+}
+static pthread_once_t g_pool_once = PTHREAD_ONCE_INIT;
+static void pool_register_atfork(void) { pthread_atfork(NULL, NULL, pool_reset_in_child); }
+
 void th_pool_run(int nthreads, void (*fn)(void *arg, long chunk), void *arg, long nchunks)
 {
     if (nchunks <= 0) return;
+    pthread_once(&g_pool_once, pool_register_atfork);
     if (nthreads > nchunks) nthreads = (int)nchunks;
     if (nthreads > TH_POOL_MAX + 1) nthreads = TH_POOL_MAX + 1;
     if (nthreads <= 1) {
