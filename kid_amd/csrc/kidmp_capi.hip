@@ -1167,7 +1167,8 @@ int kidmp_batch_step_host_multi(kidmp_multi *m, int64_t ncol, int32_t nz, double
     if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return mfail(m, KIDMP_EINVAL, "kidmp_batch_step_host_multi: bad ncol / nz");
     const int nctx = int(m->ctx.size());
     std::vector<int> rc(size_t(nctx), KIDMP_OK);
-    std::vector<std::string> msg(size_t(nctx), std::string());
+    std::vector<std::string> msg;
+    msg.resize(size_t(nctx));
     auto work = [&](int i) {
         int64_t lo = 0, hi = 0;
         kidmp_shard_bounds(ncol, nctx, i, &lo, &hi);
