@@ -5,8 +5,8 @@ One "step" = one mp_thompson advance (dt = 10 s) of every column of the batch, s
 Headline workload = BASELINE.json configs[2]: 10^5 perturbed mixed-phase deep-convection columns (ice, snow and
 graupel active), fp64, per GPU -- the largest single-GPU configuration (BASELINE.json's metric names no config).
 Weak scaling: every rank owns its own columns, no halo, no data-path collective; RCCL only for the final diagnostics
-reduction: one all-gather of the 4 precipitation sums per rank (the domain means of W:248-303), reduced locally, inside
-the timed region; the optional max-q / negative-value scan of the end state runs after the clock and only
+reduction: one all-gather of the per-rank exact precipitation accumulators (the domain means of W:248-303; 24 int64 limbs,
+summed locally: the same digits for every rank count), inside the timed region; the optional max-q / negative-value scan of the end state runs after the clock and only
 feeds the printed line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload config2|config3|config4|config5]
@@ -486,8 +486,9 @@ def run_rank(args):
             "data": "none (launcher rehearsal without a GPU; no physics ran)" if rehearse else "synthetic",
             "config": {"workload": res["workload"], "ncol_per_gpu": ncol, "nz": NZ, "dt": DT,
                        "parallelism": "columns sharded over ranks, no halo, no data-path collective; one RCCL "
-                                      "all-gather of the per-rank precipitation sums (the domain means of W:248-303), reduced locally, inside "
-                                      "the timed region; the optional max-q / negative-value scan runs after the clock"},
+                                      "all-gather of the per-rank exact (int64 fixed-point) precipitation accumulators -- the domain "
+                                      "means of W:248-303 --, summed locally, inside the timed region: identical sums for every "
+                                      "rank count; the optional max-q / negative-value scan runs after the clock"},
             "precip_domain_sums": res["precip_domain_sums"],
             "sanity_max_qc_qr_nr_qs_qi_qg_ni": res["sanity_max_qc_qr_nr_qs_qi_qg_ni"],
             "negative_values": res["negative_values"],
