@@ -24,6 +24,9 @@ ap.add_argument("--workloads", nargs="+", default=["config3", "config5", "config
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--ncol", type=int, default=0)
+ap.add_argument("--fresh", action="store_true",
+                help="every timed launch starts from the workload's initial state (restored outside the event pair): for "
+                     "truncated builds (tools/pass1_blocks.sh), whose state does not evolve, so that all builds do the same work")
 args = ap.parse_args()
 vp = C.c_void_p
 
@@ -90,8 +93,22 @@ for w in args.workloads:
             step(i, *states[i])
     torch.cuda.synchronize()
     times = [[] for _ in libs]
+    pristine = fresh() if args.fresh else None
     for rep in range(args.reps):
         for i in range(len(libs)):
+            if args.fresh:
+                tot = 0.0
+                for _ in range(args.steps):
+                    for k in pristine:
+                        states[i][0][k].copy_(pristine[k])
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    step(i, *states[i])
+                    e1.record()
+                    torch.cuda.synchronize()
+                    tot += e0.elapsed_time(e1)
+                times[i].append(tot / args.steps)
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(args.steps):
