@@ -137,12 +137,14 @@ def make_workload(name, ncol, rank=0):
     raise SystemExit("unknown workload " + name)
 
 
-def load_pmc_profile(workload, ncol, fingerprint):
-    """The committed rocprofv3 --pmc run of this workload (profiles/rNN_pmc_<workload>.json, made by
-    tools/pmc_profile.sh; counters come from separate passes), or None when it was measured on another build of
-    the kernel: the profile carries the code object's fingerprint (kidmp_kernel_fingerprint) and must match."""
+def load_pmc_profile(workload, ncol, fingerprint, arith="p64"):
+    """The committed rocprofv3 --pmc run of this workload and arithmetic (profiles/rNN_pmc_<workload>[_<arith>].json,
+    made by tools/pmc_profile.sh; counters come from separate passes), or None when it was measured on another build
+    of the kernel: the profile carries the code object's fingerprint (kidmp_kernel_fingerprint) and must match."""
     import glob
     w = "config3" if workload == "config4" else workload          # config 4 is config 3's recipe
+    if arith != "p64":
+        w += "_" + arith
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_%s.json" % w)))
     if not found:
         return None
@@ -213,6 +215,10 @@ def host_cores():
         except (OSError, ValueError):
             pass
     return n, how
+
+
+ACCURACY_COLUMNS = {"config2": 2048, "config3": 20000, "config4": 20000, "config5": 20000}   # replicas need no more; the
+# perturbed workloads show their accuracy tail (conditioning of the saturation adjustment) only on samples of this size
 
 
 def accuracy_leg(model, st, iiwarm, nacc=2048):
@@ -423,14 +429,12 @@ def run_rank(args):
         algo_bytes = ALGO_BYTES_FP64 if args.arith == "p64" else ALGO_BYTES_FP64 // 2      # fp32 9 616 B
         achieved = algo_bytes * ncol / kern_s
         fp = shard.model.kernel_fingerprint()
-        prof = load_pmc_profile(res["name"], ncol, fp)
+        prof = load_pmc_profile(res["name"], ncol, fp, args.arith)
         out = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "frac": achieved / HBM_PEAK, "traffic": None, "traffic_bytes_per_launch": None, "valu_frac": None,
                "valu_busy_frac": None,
                "kernel": shard.model.kernel_name(), "kernel_ms": res["kernel_ms"], "kernel_fingerprint": fp,
                "algorithmic_bytes_per_column_step": algo_bytes}
-        if args.arith != "p64":
-            prof = None                                       # the committed PMC profiles are of the p64 code object
         if res["iiwarm"] and args.arith == "p64":
             out["frac_warm_only_bytes"] = ALGO_BYTES_WARM * ncol / kern_s / HBM_PEAK
             out["algorithmic_bytes_warm_only"] = ALGO_BYTES_WARM
@@ -440,7 +444,7 @@ def run_rank(args):
             per_col = (2.0 * prof["FETCH_SIZE"] + prof["WRITE_SIZE"]) * 1024.0 / float(prof["ncol"])
             out["traffic_bytes_per_launch"] = per_col * ncol
             out["traffic"] = per_col * ncol / kern_s / 1e9
-            out["traffic_over_algorithmic"] = per_col / ALGO_BYTES_FP64
+            out["traffic_over_algorithmic"] = per_col / algo_bytes
             out["profile"] = prof["_file"]
         note = ("fp64 transcendental-bound path (SURVEY 8d): the HBM fraction is reported as mandated; valu_frac = "
                 "VALU instructions per column-step (rocprofv3 --pmc profile of this code object) x 4 cycles / "
@@ -499,7 +503,7 @@ def run_rank(args):
     if args.arith != "p64":
         args.no_cpu_baseline = args.no_other_workloads = True   # the accuracy leg and the companion workloads are the p64 build's
     if not rehearse and not args.no_cpu_baseline and world == 1:   # N = 1 only: the host cores are shared by the ranks
-        out["accuracy"] = accuracy_leg(shard.model, st, res["iiwarm"])
+        out["accuracy"] = accuracy_leg(shard.model, st, res["iiwarm"], ACCURACY_COLUMNS[args.workload])
         out["cpu_baseline"] = cpu_baseline(st, res["iiwarm"])
         out["gpu_over_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     if not rehearse and not args.no_host_entry and not args.no_cpu_baseline and world == 1 and args.arith == "p64":
@@ -510,7 +514,9 @@ def run_rank(args):
 
     # ---- the other configs of BASELINE.json, same process, after the headline (default run only) ----
     if not rehearse and not args.no_other_workloads and args.workload == "config3" and not args.ncol:
-        others = ["config2", "config5"] if world == 1 else ["config4"]
+        # config 4 (10^6 columns over 8 GPUs) is represented by ONE of its 125 000-column shards at N = 1 and by a shard per
+        # rank at N > 1 (10^6 at N = 8)
+        others = ["config2", "config5", "config4"] if world == 1 else ["config4"]
         lines = []
         for name in others:
             shard, st, r = time_workload(name, DEFAULT_NCOL[name], args.steps, min(args.warmup, 3))
@@ -519,8 +525,9 @@ def run_rank(args):
                         "ms_per_step": r["ms_per_step"], "n_gpus": world, "roofline": roofline(shard, r),
                         "precip_domain_sums": r["precip_domain_sums"], "negative_values": r["negative_values"]}
                 if world == 1 and not args.no_cpu_baseline:
-                    line["accuracy"] = accuracy_leg(shard.model, st, r["iiwarm"])
-                    line["cpu_baseline"] = cpu_baseline(st, r["iiwarm"], budget_s=5.0)
+                    line["accuracy"] = accuracy_leg(shard.model, st, r["iiwarm"], ACCURACY_COLUMNS[name])
+                    if name != "config4":                     # config 4 is config 3's recipe: its CPU baseline is the headline's
+                        line["cpu_baseline"] = cpu_baseline(st, r["iiwarm"], budget_s=5.0)
                 lines.append(line)
             shard.close()
             del shard, st

@@ -146,6 +146,10 @@ int kidmp32_batch_step_device(kidmp_ctx *ctx, int64_t ncol, int32_t nz, float dt
                               float *ppt, double *rates, int32_t *nstep,
                               int32_t arith, void *stream);
 
+/* DEPRECATED, kept for hosts linked against earlier builds: rounds 1-2 reserved a per-batch work profile here.  The step
+ * owns no per-batch device memory any more; the call checks its arguments, does nothing and returns KIDMP_OK. */
+int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz);
+
 /* The device entries own no per-batch device memory and never allocate: they can be captured into a hipGraph as
  * they are, and one context may have STEP launches in flight on several streams.  (The diagnostics entries further
  * down -- kidmp_reduce_rates_device, kidmp_sanity_device -- use one scratch buffer per context, allocated by
@@ -199,6 +203,7 @@ int kidmp_ppt_limbs_to_sums(const int64_t *limbs, double *out4);
  * no other exchange.  Results per column are those of kidmp_batch_step_host_diag bit for bit, the sums are identical
  * for every device list.  A device may be named twice (two contexts on one card).  Optional arrays as above. */
 typedef struct kidmp_multi kidmp_multi;
+#define KIDMP_MAX_DEVICE_LIST 16     /* entries of devices[]; a process may hold 32 contexts at once */
 int kidmp_init_multi(const kidmp_cfg *cfg, int32_t ndev, const int32_t *devices, kidmp_multi **out);   /* cfg->device is ignored */
 void kidmp_finalize_multi(kidmp_multi *m);
 const char *kidmp_multi_last_error(const kidmp_multi *m);
@@ -211,6 +216,18 @@ int kidmp_batch_step_host_multi(kidmp_multi *m, int64_t ncol, int32_t nz, double
                                 double *nc, double *nwfa, double *nifa, double *t,
                                 const double *p, const double *w, const double *dz,
                                 double *ppt, double *rates, int32_t *nstep, double *precip_sums);
+/* The same call with the sanity scan of the scheme's 3-D driver (M:1025-1094) over the END state of all ncol columns:
+ * sanity15 (host, may be NULL) = what kidmp_sanity_device returns for the unsharded batch -- [0..6] maxima of qc, qr, nr,
+ * qs, qi, qg, ni, [7..14] numbers of negative entries of qc, qr, nr, qs, qi, qg, ni, qv --, scanned chunk by chunk on each
+ * device as the chunks leave the step (exact integer atomics) and reduced over the devices beside the precipitation
+ * limbs, in the same RCCL group: all-reduce(uint64, MAX) of the seven maxima (non-negative doubles order like their bit
+ * patterns), all-reduce(uint64, SUM) of the eight counts.  Identical for every device list. */
+int kidmp_batch_step_host_multi_diag(kidmp_multi *m, int64_t ncol, int32_t nz, double dt,
+                                     double *qv, double *qc, double *qi, double *qr,
+                                     double *qs, double *qg, double *ni, double *nr,
+                                     double *nc, double *nwfa, double *nifa, double *t,
+                                     const double *p, const double *w, const double *dz,
+                                     double *ppt, double *rates, int32_t *nstep, double *precip_sums, double *sanity15);
 
 /* Optional domain diagnostics beyond the four precipitation sums.
  * kidmp_reduce_rates_device: out[KIDMP_NRATES*nz] (device) = sum over columns of rates[col][r][k] -- the mean

@@ -418,7 +418,7 @@ struct PipelineDrain {
 
 template <class T, class Launch>
 int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const *io, const T *const *in, T *ppt,
-                  double *rates, int32_t *nstep, Launch launch, bool exact_sums = false)
+                  double *rates, int32_t *nstep, Launch launch, bool exact_sums = false, bool scan_sanity = false)
 {
     if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
     // Arrays the caller may leave out (NULL), as KiD itself does (W:36 passes nc1d, nwfa1d, nifa1d unset; a warm run
@@ -443,9 +443,10 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
     if (int rc = check_step_args(ctx, ncol, nz, dt, ptrs, np)) return rc;
     if (has_w && !in[2] && ncol > 0) return fail(ctx, KIDMP_EINVAL, "kidmp: an aerosol-aware context needs the updraft profile w");
     if (ncol == 0) {
-        if (exact_sums) {
+        if (exact_sums || scan_sanity) {
             GUARD(ctx);
-            HIPTRY(ctx, hipMemset(ctx->d_acc, 0, ACC_N * sizeof(unsigned long long)));
+            if (exact_sums) HIPTRY(ctx, hipMemset(ctx->d_acc, 0, ACC_N * sizeof(unsigned long long)));
+            if (scan_sanity) HIPTRY(ctx, hipMemset(ctx->d_sanity, 0, 15 * sizeof(unsigned long long)));
         }
         return KIDMP_OK;
     }
@@ -472,6 +473,7 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
     char *const base = reinterpret_cast<char *>(ctx->d_stage);
     PipelineDrain drain{ctx};
     if (exact_sums) HIPTRY(ctx, hipMemsetAsync(ctx->d_acc, 0, ACC_N * sizeof(unsigned long long), ctx->stream));
+    if (scan_sanity) HIPTRY(ctx, hipMemsetAsync(ctx->d_sanity, 0, 15 * sizeof(unsigned long long), ctx->stream));
     for (int64_t i = 0; i < nchunk; ++i) {
         const int b = int(i % nbuf);
         const int64_t c0 = i * CH, n = (c0 + CH <= ncol ? CH : ncol - c0);
@@ -504,6 +506,14 @@ int host_pipeline(kidmp_ctx *ctx, int64_t ncol, int32_t nz, double dt, T *const 
         }
         if (int rc = launch(n, dio, din, dppt, drates, dnstep)) return rc;
         if (exact_sums) HIPTRY(ctx, launch_ppt_exact<T>(n, dppt, ctx->d_acc, ctx->stream));   // the chunk's share of the domain sums
+        if constexpr (std::is_same<T, double>::value)
+            if (scan_sanity) {                                // the scan of M:1025-1094 over the chunk's end state (exact integer atomics)
+                SanityPtrs sp{{dio[1], dio[3], dio[7], dio[4], dio[2], dio[5], dio[6], dio[0]}};
+                int64_t g = (int64_t(cnt) + 255) / 256;
+                if (g > 2048) g = 2048;
+                hipLaunchKernelGGL(k_sanity, dim3((unsigned)g), dim3(256), 0, ctx->stream, int64_t(cnt), sp, ctx->d_sanity);
+                HIPTRY(ctx, hipGetLastError());
+            }
         HIPTRY(ctx, hipEventRecord(ctx->ev_step[b], ctx->stream));
         // download
         HIPTRY(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->ev_step[b], 0));
@@ -1119,7 +1129,7 @@ void kidmp_finalize_multi(kidmp_multi *m)
 
 int kidmp_init_multi(const kidmp_cfg *cfg, int32_t ndev, const int32_t *devices, kidmp_multi **out)
 {
-    if (!cfg || !out || !devices || ndev < 1 || ndev > MAX_CONST_SLOTS) return fail(nullptr, KIDMP_EINVAL, "kidmp_init_multi: bad argument (1..8 devices)");
+    if (!cfg || !out || !devices || ndev < 1 || ndev > KIDMP_MAX_DEVICE_LIST) return fail(nullptr, KIDMP_EINVAL, "kidmp_init_multi: bad argument (1..16 devices)");
     *out = nullptr;
     kidmp_multi *m = new (std::nothrow) kidmp_multi;
     if (!m) return fail(nullptr, KIDMP_ENOMEM, "kidmp_init_multi: out of host memory");
@@ -1157,77 +1167,163 @@ int32_t kidmp_multi_size(const kidmp_multi *m) { return m ? int32_t(m->ctx.size(
 kidmp_ctx *kidmp_multi_context(kidmp_multi *m, int32_t i) { return m && i >= 0 && size_t(i) < m->ctx.size() ? m->ctx[size_t(i)] : nullptr; }
 const char *kidmp_multi_last_error(const kidmp_multi *m) { return m && !m->err.empty() ? m->err.c_str() : g_err.c_str(); }
 
-int kidmp_batch_step_host_multi(kidmp_multi *m, int64_t ncol, int32_t nz, double dt,
-                                double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
-                                double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
-                                const double *p, const double *w, const double *dz, double *ppt, double *rates,
-                                int32_t *nstep, double *precip_sums)
+int kidmp_batch_step_host_multi_diag(kidmp_multi *m, int64_t ncol, int32_t nz, double dt,
+                                     double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
+                                     double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
+                                     const double *p, const double *w, const double *dz, double *ppt, double *rates,
+                                     int32_t *nstep, double *precip_sums, double *sanity15)
 {
     if (!m || m->ctx.empty()) return mfail(m, KIDMP_ESTATE, "kidmp_batch_step_host_multi: not initialised");
     if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return mfail(m, KIDMP_EINVAL, "kidmp_batch_step_host_multi: bad ncol / nz");
     const int nctx = int(m->ctx.size());
-    std::vector<int> rc(size_t(nctx), KIDMP_OK);
+    // Nothing below may throw through the C boundary: allocation failures (std::bad_alloc from the vectors, std::system_error
+    // from std::thread) are mapped to a status code, and threads that did start are joined before the function returns.
+    std::vector<int> rc;
     std::vector<std::string> msg;
-    msg.resize(size_t(nctx));
-    auto work = [&](int i) {
-        int64_t lo = 0, hi = 0;
-        kidmp_shard_bounds(ncol, nctx, i, &lo, &hi);
-        const size_t o = size_t(lo) * size_t(nz);
-        auto at = [o](double *a) { return a ? a + o : nullptr; };
-        auto atc = [o](const double *a) { return a ? a + o : nullptr; };
-        kidmp_ctx *c = m->ctx[size_t(i)];
-        double *io[12] = {at(qv), at(qc), at(qi), at(qr), at(qs), at(qg), at(ni), at(nr), at(nc), at(nwfa), at(nifa), at(t)};
-        const double *in[3] = {atc(p), atc(dz), atc(w)};
-        rc[size_t(i)] = host_pipeline<double>(c, hi - lo, nz, dt, io, in, ppt ? ppt + 4 * lo : nullptr,
-            rates ? rates + size_t(KIDMP_NRATES) * o : nullptr, nstep ? nstep + 4 * lo : nullptr,
-            [&](int64_t n, double *const *d, const double *const *f, double *dppt, double *drates, int32_t *dnstep) {
-                return kidmp_batch_step_device(c, n, nz, dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11],
-                                               f[0], f[2], f[1], dppt, drates, dnstep, c->stream);
-            }, true);
-        if (rc[size_t(i)] != KIDMP_OK) msg[size_t(i)] = kidmp_last_error(c);
+    std::vector<int64_t> limbs, lead;
+    std::vector<unsigned long long> san, san_lead;
+    std::vector<std::thread> th;
+    try {
+        rc.assign(size_t(nctx), KIDMP_OK);
+        msg.resize(size_t(nctx));
+        limbs.resize(size_t(nctx) * ACC_N);
+        lead.assign(m->leader.size() * ACC_N, 0);
+        san.resize(size_t(nctx) * 15);
+        san_lead.assign(m->leader.size() * 15, 0ull);
+        th.reserve(size_t(nctx));
+    } catch (const std::exception &) {
+        return mfail(m, KIDMP_ENOMEM, "kidmp_batch_step_host_multi: out of host memory");
+    }
+    auto work = [&](int i) noexcept {
+        try {
+            int64_t lo = 0, hi = 0;
+            kidmp_shard_bounds(ncol, nctx, i, &lo, &hi);
+            const size_t o = size_t(lo) * size_t(nz);
+            auto at = [o](double *a) { return a ? a + o : nullptr; };
+            auto atc = [o](const double *a) { return a ? a + o : nullptr; };
+            kidmp_ctx *c = m->ctx[size_t(i)];
+            double *io[12] = {at(qv), at(qc), at(qi), at(qr), at(qs), at(qg), at(ni), at(nr), at(nc), at(nwfa), at(nifa), at(t)};
+            const double *in[3] = {atc(p), atc(dz), atc(w)};
+            rc[size_t(i)] = host_pipeline<double>(c, hi - lo, nz, dt, io, in, ppt ? ppt + 4 * lo : nullptr,
+                rates ? rates + size_t(KIDMP_NRATES) * o : nullptr, nstep ? nstep + 4 * lo : nullptr,
+                [&](int64_t n, double *const *d, const double *const *f, double *dppt, double *drates, int32_t *dnstep) {
+                    return kidmp_batch_step_device(c, n, nz, dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], d[8], d[9], d[10], d[11],
+                                                   f[0], f[2], f[1], dppt, drates, dnstep, c->stream);
+                }, true, sanity15 != nullptr);
+            if (rc[size_t(i)] != KIDMP_OK) msg[size_t(i)] = kidmp_last_error(c);
+        } catch (const std::bad_alloc &) {
+            rc[size_t(i)] = KIDMP_ENOMEM;
+        } catch (...) {
+            rc[size_t(i)] = KIDMP_EHIP;
+        }
     };
     // one host thread per context: HIP's current device and the pipeline's blocking waits are per thread
-    std::vector<std::thread> th;
-    for (int i = 1; i < nctx; ++i) th.emplace_back(work, i);
-    work(0);
+    int started = 0;
+    bool thread_failure = false;
+    for (int i = 1; i < nctx; ++i) {
+        try {
+            th.emplace_back(work, i);
+            ++started;
+        } catch (const std::exception &) {                     // std::system_error: no more threads
+            thread_failure = true;
+            break;
+        }
+    }
+    if (!thread_failure) work(0);
     for (auto &x : th) x.join();
+    if (thread_failure)
+        return mfail(m, KIDMP_ENOMEM, "kidmp_batch_step_host_multi: could not start a host thread per context (" +
+                                      std::to_string(started) + " of " + std::to_string(nctx - 1) + " started, joined; nothing was stepped on the others)");
     for (int i = 0; i < nctx; ++i)
-        if (rc[size_t(i)] != KIDMP_OK) return mfail(m, rc[size_t(i)], "device " + std::to_string(m->ctx[size_t(i)]->cfg.device) + ": " + msg[size_t(i)]);
-    if (!precip_sums) return KIDMP_OK;
-    // ---- the domain sums: contexts that share a device add their limbs, then ONE all-reduce over the devices ----
-    std::vector<int64_t> limbs(size_t(nctx) * ACC_N), lead(m->leader.size() * ACC_N, 0);
+        if (rc[size_t(i)] != KIDMP_OK)
+            return mfail(m, rc[size_t(i)], "device " + std::to_string(m->ctx[size_t(i)]->cfg.device) + ": " +
+                                           (msg[size_t(i)].empty() ? std::string("host-side failure in the context's worker thread") : msg[size_t(i)]));
+    if (!precip_sums && !sanity15) return KIDMP_OK;
+    // ---- the domain diagnostics: contexts that share a device combine their accumulators on the host, then the devices
+    //      exchange them: all-reduce(int64, SUM) of the 24 precipitation limbs and -- on request, the analogue of the scan
+    //      of M:1025-1094 -- all-reduce(uint64, MAX) of the 7 maxima (bit patterns of non-negative doubles order like the
+    //      values) and all-reduce(uint64, SUM) of the 8 negative-entry counts, in ONE RCCL group ----
+    // A leader's stream must be idle before this function returns on ANY path (queued collectives / copies).
+    struct DrainLeaders {
+        kidmp_multi *m;
+        ~DrainLeaders()
+        {
+            for (int l : m->leader) {
+                kidmp_ctx *c = m->ctx[size_t(l)];
+                DeviceGuard g(c->cfg.device);
+                (void)hipStreamSynchronize(c->stream);
+            }
+        }
+    } drain_leaders{m};
     for (int i = 0; i < nctx; ++i) {
         kidmp_ctx *c = m->ctx[size_t(i)];
         DeviceGuard g(c->cfg.device);
-        const hipError_t e = hipMemcpy(&limbs[size_t(i) * ACC_N], c->d_acc, ACC_N * sizeof(int64_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("hipMemcpy(limbs): ") + hipGetErrorString(e));
+        hipError_t e = hipMemcpy(&limbs[size_t(i) * ACC_N], c->d_acc, ACC_N * sizeof(int64_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && sanity15) e = hipMemcpy(&san[size_t(i) * 15], c->d_sanity, 15 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("hipMemcpy(accumulators): ") + hipGetErrorString(e));
+        const size_t L = size_t(m->leader_of[size_t(i)]);
         for (int q = 0; q < ACC_N; ++q)                                    // wrap-around addition == two's complement sum
-            lead[size_t(m->leader_of[size_t(i)]) * ACC_N + q] = int64_t(uint64_t(lead[size_t(m->leader_of[size_t(i)]) * ACC_N + q]) + uint64_t(limbs[size_t(i) * ACC_N + q]));
+            lead[L * ACC_N + q] = int64_t(uint64_t(lead[L * ACC_N + q]) + uint64_t(limbs[size_t(i) * ACC_N + q]));
+        if (sanity15)
+            for (int q = 0; q < 15; ++q) {
+                const unsigned long long v = san[size_t(i) * 15 + q];
+                san_lead[L * 15 + q] = q < 7 ? (v > san_lead[L * 15 + q] ? v : san_lead[L * 15 + q]) : san_lead[L * 15 + q] + v;
+            }
     }
-    for (size_t l = 0; l < m->leader.size(); ++l) {
-        kidmp_ctx *c = m->ctx[size_t(m->leader[l])];
+    for (size_t l = 0; l < m->leader.size(); ++l) {                        // 192 + 120 bytes per device: synchronous copies,
+        kidmp_ctx *c = m->ctx[size_t(m->leader[l])];                       // so that no DMA ever reads a host buffer after this scope
         DeviceGuard g(c->cfg.device);
-        const hipError_t e = hipMemcpyAsync(c->d_acc, &lead[l * ACC_N], ACC_N * sizeof(int64_t), hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("hipMemcpyAsync(limbs): ") + hipGetErrorString(e));
+        hipError_t e = hipMemcpy(c->d_acc, &lead[l * ACC_N], ACC_N * sizeof(int64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess && sanity15) e = hipMemcpy(c->d_sanity, &san_lead[l * 15], 15 * sizeof(unsigned long long), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("hipMemcpy(accumulators, to device): ") + hipGetErrorString(e));
     }
     ncclResult_t r = g_rccl.GroupStart();
     for (size_t l = 0; l < m->leader.size() && r == ncclSuccess; ++l) {
         kidmp_ctx *c = m->ctx[size_t(m->leader[l])];
         DeviceGuard g(c->cfg.device);
         r = g_rccl.AllReduce(c->d_acc, c->d_acc, ACC_N, ncclInt64, ncclSum, m->comm[l], c->stream);
+        if (r == ncclSuccess && sanity15) r = g_rccl.AllReduce(c->d_sanity, c->d_sanity, 7, ncclUint64, ncclMax, m->comm[l], c->stream);
+        if (r == ncclSuccess && sanity15) r = g_rccl.AllReduce(c->d_sanity + 7, c->d_sanity + 7, 8, ncclUint64, ncclSum, m->comm[l], c->stream);
     }
     const ncclResult_t r2 = g_rccl.GroupEnd();
     if (r == ncclSuccess) r = r2;
     if (r != ncclSuccess) return mfail(m, KIDMP_EHIP, std::string("ncclAllReduce: ") + g_rccl.GetErrorString(r));
     int64_t total[ACC_N];
-    for (size_t l = 0; l < m->leader.size(); ++l) {                        // every device holds the same sums; all are drained
+    unsigned long long stot[15];
+    for (size_t l = 0; l < m->leader.size(); ++l) {                        // every device holds the same results; all are drained
         kidmp_ctx *c = m->ctx[size_t(m->leader[l])];
         DeviceGuard g(c->cfg.device);
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e == hipSuccess && l == 0) e = hipMemcpy(total, c->d_acc, sizeof(total), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("all-reduce of the precipitation sums: ") + hipGetErrorString(e));
+        if (e == hipSuccess && l == 0 && sanity15) e = hipMemcpy(stot, c->d_sanity, sizeof(stot), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return mfail(m, KIDMP_EHIP, std::string("all-reduce of the domain diagnostics: ") + hipGetErrorString(e));
     }
-    limbs_to_sums(total, precip_sums);
+    if (precip_sums) limbs_to_sums(total, precip_sums);
+    if (sanity15)
+        for (int q = 0; q < 15; ++q) {
+            double v;
+            if (q < 7) memcpy(&v, &stot[q], sizeof(v)); else v = double(stot[q]);
+            sanity15[q] = v;
+        }
+    return KIDMP_OK;
+}
+
+int kidmp_batch_step_host_multi(kidmp_multi *m, int64_t ncol, int32_t nz, double dt,
+                                double *qv, double *qc, double *qi, double *qr, double *qs, double *qg,
+                                double *ni, double *nr, double *nc, double *nwfa, double *nifa, double *t,
+                                const double *p, const double *w, const double *dz, double *ppt, double *rates,
+                                int32_t *nstep, double *precip_sums)
+{
+    return kidmp_batch_step_host_multi_diag(m, ncol, nz, dt, qv, qc, qi, qr, qs, qg, ni, nr, nc, nwfa, nifa, t, p, w, dz, ppt, rates,
+                                            nstep, precip_sums, nullptr);
+}
+
+/* deprecated: device memory is no longer reserved per batch (launches own no per-batch memory since round 2); kept so that
+ * hosts linked against earlier builds keep linking.  Checks its arguments and does nothing. */
+int kidmp_reserve(kidmp_ctx *ctx, int64_t ncol, int32_t nz)
+{
+    if (!ctx || !ctx->ready) return fail(ctx, KIDMP_ESTATE, "kidmp: context not initialised");
+    if (ncol < 0 || nz < 2 || nz > KIDMP_MAX_NZ) return fail(ctx, KIDMP_EINVAL, "kidmp_reserve: bad ncol / nz");
     return KIDMP_OK;
 }
 

@@ -9,8 +9,8 @@
 
 namespace kidmp {
 
-constexpr int KIDMP_NRATES_ = 36;
-constexpr int MAX_CONST_SLOTS = 8;   // contexts alive at once per process (constant-memory slots)    // save_dg rates per level, order of M:2967-3119
+constexpr int KIDMP_NRATES_ = 36;    // save_dg rates per level, order of M:2967-3119
+constexpr int MAX_CONST_SLOTS = 32;  // contexts alive at once per process (constant-memory slots)
 
 // All pointers are device pointers; profiles are x[col*nz + k] (k fastest).  R = the reference's REAL in the
 // arithmetic variant that is launched: double (p64) or float (p32n, f32).

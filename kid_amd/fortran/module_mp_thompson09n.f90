@@ -246,6 +246,8 @@ contains
           pos = pos + nxt
        end do
        kidmp_ndevices = n
+       ! a list with ONE entry names the card of the single-device path (KIDMP_DEVICES=3 must not land on GPU 0)
+       if (n == 1) kidmp_device = kidmp_devices(1)
     end if
     cfg%device = int(kidmp_device, c_int32_t)
     cfg%is_aerosol_aware = merge(1_c_int32_t, 0_c_int32_t, is_aerosol_aware)
@@ -281,7 +283,8 @@ contains
           wr = merge(1_c_int32_t, 0_c_int32_t, i == 1)
           rc = kidmp_table_cache_reuse(c, cdir, reuse, wr, status)
           call stop_on_error(rc, 'thompson_init (table cache)')
-          if (i == 1 .and. iand(status, 3_c_int32_t) /= 0) then          ! the reference's notice, M:3872-3881
+          if (i == 1 .and. iand(status, 2_c_int32_t) /= 0) then          ! the reference's notice: printed by qr_acr_qs only
+             ! (M:3872-3881; qr_acr_qg reads its file silently, M:3721-3727), i.e. when the racs file was read (bit 1)
              write(6,*) ' !!!!!!!!!!!!!!!!!! WARNING !!!!!!!!!!!!!!!!!!!'
              write(6,*) ' Reading in pre-calculated lookup tables in    '
              write(6,*) ' Thompson scheme'

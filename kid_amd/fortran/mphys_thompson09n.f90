@@ -56,6 +56,7 @@ contains
     real, pointer :: st(:,:,:), fo(:,:,:), ppt(:,:)
     real, allocatable, target, save :: st_own(:,:,:), fo_own(:,:,:), ppt_own(:,:)
     real, allocatable, save :: total(:)
+    real, allocatable, save :: pptrain_2d_prof(:,:)          ! W:32; saved as 'total_ppt_level' for nx > 1 (W:304-307)
     real :: rho
     logical :: staged
     integer :: i, k, m, s
@@ -176,8 +177,15 @@ contains
        end do
        name = 'total_surface_ppt'
        call save_dg(total, name, i_dgtime, units, dim='time')
-       ! 'total_ppt_level' (W:305-307) would save pptrain_2d_prof, an array the reference never assigns
-       ! (W:191 is commented out): not emitted.
+       ! save precip flux at all levels and columns, W:304-307.  The reference saves pptrain_2d_prof(nz,nx), an array it
+       ! never assigns (W:191 is commented out), i.e. undefined values under a name every stock KiD output carries.
+       ! Defined semantics here (U6): the name, units, dim='z,x' and shape of the reference, all values zero.
+       if (.not. allocated(pptrain_2d_prof)) then
+          allocate(pptrain_2d_prof(nz, nx))
+          pptrain_2d_prof = 0.0
+       end if
+       name = 'total_ppt_level'
+       call save_dg(pptrain_2d_prof, name, i_dgtime, units, dim='z,x')
     end if
 
   end Subroutine mphys_thompson09_interfacen

@@ -120,6 +120,10 @@ def load_library(path=None):
     L.kidmp_multi_context.argtypes = [_vp, C.c_int32]
     L.kidmp_batch_step_host_multi.restype = C.c_int
     L.kidmp_batch_step_host_multi.argtypes = [_vp, C.c_int64, C.c_int32, C.c_double] + [_dp] * 17 + [C.POINTER(C.c_int32), _dp]
+    L.kidmp_batch_step_host_multi_diag.restype = C.c_int
+    L.kidmp_batch_step_host_multi_diag.argtypes = [_vp, C.c_int64, C.c_int32, C.c_double] + [_dp] * 17 + [C.POINTER(C.c_int32), _dp, _dp]
+    L.kidmp_reserve.restype = C.c_int
+    L.kidmp_reserve.argtypes = [_vp, C.c_int64, C.c_int32]
     L.kidmp_math_probe.restype = C.c_int
     L.kidmp_math_probe.argtypes = [_vp, C.c_int32, C.c_int64, _dp, _dp, _dp]
     L.kidmp_get_table.restype = C.c_int64
@@ -376,6 +380,11 @@ class ThompsonMP:
         self._check(load_library().kidmp_reduce_rates_device(self._h, ncol, nz, rates.data_ptr(), out.data_ptr(), s))
         return out
 
+    def reserve(self, ncol, nz=120):
+        """Deprecated no-op (kidmp_reserve): the step owns no per-batch device memory.  Kept so that hosts written
+        against rounds 1-2 keep working; validates its arguments like every entry."""
+        self._check(load_library().kidmp_reserve(self._h, int(ncol), int(nz)))
+
     SANITY_MAX = ("qc", "qr", "nr", "qs", "qi", "qg", "ni")
     SANITY_NEG = ("qc", "qr", "nr", "qs", "qi", "qg", "ni", "qv")
 
@@ -505,9 +514,10 @@ class ThompsonMulti:
         except Exception:
             pass
 
-    def batch_step_host(self, st, dt, ppt=None, want_rates=False, want_nstep=False):
+    def batch_step_host(self, st, dt, ppt=None, want_rates=False, want_nstep=False, want_sanity=False):
         """numpy float64 [ncol, nz] arrays, in place (optional keys as ThompsonMP.batch_step_host).
-        Returns (ppt, rates or None, nstep or None, precip_sums[4])."""
+        Returns (ppt, rates or None, nstep or None, precip_sums[4]) -- with want_sanity a fifth element, the 15-number
+        sanity scan of the end state (kidmp_batch_step_host_multi_diag), reduced over the devices like the sums."""
         ncol, nz = st["qv"].shape
         ptrs = []
         for k in STATE_NAMES + FORCING_NAMES:
@@ -524,12 +534,17 @@ class ThompsonMulti:
         nstep = np.zeros((ncol, 4), dtype=np.int32) if want_nstep else None
         sums = np.zeros(4)
         L = load_library()
-        rc = L.kidmp_batch_step_host_multi(self._h, ncol, nz, float(dt), *ptrs, _np_ptr(ppt),
-                                           _np_ptr(rates) if want_rates else None,
-                                           nstep.ctypes.data_as(C.POINTER(C.c_int32)) if want_nstep else None, _np_ptr(sums))
+        a_rates = _np_ptr(rates) if want_rates else None
+        a_nstep = nstep.ctypes.data_as(C.POINTER(C.c_int32)) if want_nstep else None
+        if want_sanity:
+            sanity = np.zeros(15)
+            rc = L.kidmp_batch_step_host_multi_diag(self._h, ncol, nz, float(dt), *ptrs, _np_ptr(ppt), a_rates, a_nstep,
+                                                    _np_ptr(sums), _np_ptr(sanity))
+        else:
+            rc = L.kidmp_batch_step_host_multi(self._h, ncol, nz, float(dt), *ptrs, _np_ptr(ppt), a_rates, a_nstep, _np_ptr(sums))
         if rc != 0:
             raise KidmpError("kidmp_batch_step_host_multi failed (%d): %s" % (rc, L.kidmp_multi_last_error(self._h).decode()))
-        return ppt, rates, nstep, sums
+        return (ppt, rates, nstep, sums, sanity) if want_sanity else (ppt, rates, nstep, sums)
 
 
 # ---- module-level mirror of the Fortran module procedures ----

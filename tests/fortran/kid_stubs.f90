@@ -40,7 +40,7 @@ module diagnostics
   integer :: log_k(maxlog), log_i(maxlog)
   double precision :: log_v(maxlog)
   interface save_dg
-     module procedure save_dg_scalar, save_dg_1d, save_dg_k_dp, save_dg_ki_dp
+     module procedure save_dg_scalar, save_dg_1d, save_dg_2d, save_dg_k_dp, save_dg_ki_dp
   end interface
 contains
   subroutine put(form, name, k, i, v, units, dim)
@@ -70,6 +70,18 @@ contains
     end do
     if (.false.) print *, it
   end subroutine save_dg_1d
+  subroutine save_dg_2d(v, name, it, units, dim)                ! 2-D form, W:307 (dim='z,x')
+    real, intent(in) :: v(:,:)
+    character(*), intent(in) :: name, units, dim
+    integer, intent(in) :: it
+    integer :: i, k
+    do i = 1, size(v, 2)
+       do k = 1, size(v, 1)
+          call put('2d', name, k, i, dble(v(k,i)), units, dim)
+       end do
+    end do
+    if (.false.) print *, it
+  end subroutine save_dg_2d
   subroutine save_dg_k_dp(k, v, name, it, units, dim)           ! per-level rate form, nx == 1 (M:2967)
     integer, intent(in) :: k, it
     double precision, intent(in) :: v

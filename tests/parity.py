@@ -170,13 +170,14 @@ MAX_SENSITIVE_FRAC = 0.02   # at most this share of the levels may lean on the s
 
 def assert_parity(oracle, st, dt, got, got_ppt, tol=TOL, sens_factor=10.0, tol_ppt=None, depletion=0.0,
                   max_branch_frac=None, min_cols_within=None, tol_cols=TOL, ceiling=ABS_CEILING,
-                  max_sensitive_frac=MAX_SENSITIVE_FRAC):
+                  max_sensitive_frac=MAX_SENSITIVE_FRAC, quantile=None):
     """The parity assertion of the -m gpu tests: EVERY level within max(tol, sens_factor x the oracle's own
     sensitivity there), levels on the reference's residue-decided tests against the better of their two admissible
     outcomes; precipitation within tol_ppt.  The sensitivity allowance is itself bounded: no level beyond
     max(tol, ceiling) whatever the oracle's sensitivity there, and at most max_sensitive_frac of the levels beyond
     `tol` at all (i.e. passing only because of the allowance).  Optionally: at most max_branch_frac of the levels on
-    residue-decided tests, and at least min_cols_within of the columns with every level within tol_cols.
+    residue-decided tests, and at least min_cols_within of the columns with every level within tol_cols; `quantile` =
+    (q, bound): the q-quantile of the level errors (no allowance of any kind) must not exceed bound.
     Returns the verdict dict."""
     cmp = branch_aware_compare(oracle, st, dt, got, got_ppt, depletion=depletion)
     v = verdict(cmp, tol=tol, sens_factor=sens_factor)
@@ -185,6 +186,9 @@ def assert_parity(oracle, st, dt, got, got_ppt, tol=TOL, sens_factor=10.0, tol_p
     assert v["n_beyond_tol"] <= int(np.ceil(max_sensitive_frac * v["n_levels"])), v
     if got_ppt is not None:
         assert v["max_rel_ppt"] < (tol if tol_ppt is None else tol_ppt), v
+    if quantile is not None:
+        v["quantile"] = float(np.quantile(cmp["err"], quantile[0]))
+        assert v["quantile"] <= quantile[1], v
     if max_branch_frac is not None:
         assert v["n_branch_levels"] <= max_branch_frac * v["n_levels"], v
     if min_cols_within is not None:

@@ -165,6 +165,17 @@ def test_rate_diagnostics_mixed_nx3_names_order_values(tmp_path, oracle_mixed):
     tail = log[len(rates):]
     names = ["surface_ppt_for_rain", "surface_ppt_for_ice", "surface_ppt_for_snow", "surface_ppt_for_graupel", "total_surface_ppt"]
     cols = [ppts[:, 0], ppts[:, 3], ppts[:, 1], ppts[:, 2], ppts.sum(axis=1)]
+    # the full ordered name set of the adapter for nx > 1 (W:248-307), 'total_ppt_level' (dim='z,x', shape (nz, nx)) last
+    level = tail[2 * 5 * nx:]
+    tail = tail[: 2 * 5 * nx]
+    seen = []
+    for e in tail + level:
+        if not seen or seen[-1] != e["name"]:
+            seen.append(e["name"])
+    assert seen == names * 2 + ["total_ppt_level"], seen
+    assert len(level) == 120 * nx and all(e["form"] == "2d" and e["dim"] == "z,x" and e["units"] == "kg/kg m" for e in level)
+    assert [(e["i"], e["k"]) for e in level] == [(i + 1, k + 1) for i in range(nx) for k in range(120)]
+    assert all(e["v"] == 0.0 for e in level)          # the reference never assigns the array (W:191): defined as zeros here
     assert len(tail) == 2 * 5 * nx and all(e["form"] == "array" and e["dim"] == "time" for e in tail)
     for half, div in ((0, nx), (1, 1)):                                            # means first (W:255-275), then columns (W:283-303)
         for m in range(5):

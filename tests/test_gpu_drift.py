@@ -4,8 +4,11 @@ chain against an independent oracle chain over 60 and 360 coupled steps, branch 
 What the numbers mean: a column stays "on the oracle's branch history" while every HIP step agrees with the oracle's
 step from the same input to 1e-7; the scheme's residue-decided tests (M:3587, M:3596) and threshold crossings take the
 other columns onto a different -- equally admissible -- trajectory, after which an end-state comparison says nothing
-about arithmetic.  Bounds are statistical (measured values in profiles/r03_drift.jsonl: on-history maxima 8e-11 /
-2e-7, 99th percentiles <= 5e-12, 84 % / 99 % of the columns on the history) with two to three orders of margin."""
+about arithmetic.  Every departure is classified (drift.explain_departures: the other admissible outcome of a
+residue-decided test / the oracle's own ulp-sensitivity at the level / a discontinuity of the scheme within 2e-13 of the
+input) and NONE may stay unexplained.  Bounds are statistical (measured values in profiles/r04_drift.jsonl: on-history
+maxima 8e-11 / 1.8e-7, 99th percentiles <= 5e-12, 84 % / 99 % of the columns on the history): the maximum with one order
+of margin, the percentiles with two."""
 import pytest
 
 import cases
@@ -23,7 +26,9 @@ def test_drift_over_360_steps(gpu_mixed, oracle_mixed, name, min_on_history):
         assert r["frac_on_history"] >= min_on_history, r
         for k, v in r["vars"].items():
             h = v["on_history"]
-            assert h["median"] < 1e-11 and h["p99"] < 1e-9 and h["max"] < 1e-5, (name, r["steps"], k, h)
+            assert h["median"] < 1e-11 and h["p99"] < 1e-9 and h["max"] < 2e-6, (name, r["steps"], k, h)
         assert r["vars"]["t"]["on_history"]["max"] < 1e-12
         assert r["precip_accumulated"]["max_on_history"] < 1e-10, r["precip_accumulated"]
+        assert r["departures"]["unexplained"] == 0, (r["departures"], r["departures_not_residue"])
+        assert sum(r["departures"].values()) == r["columns"] - r["columns_on_oracle_branch_history"]
     print(name, {r["steps"]: (r["frac_on_history"], max(v["on_history"]["max"] for v in r["vars"].values())) for r in recs})

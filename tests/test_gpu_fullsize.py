@@ -63,10 +63,12 @@ def test_config2_full_size_replicas(gpu_warm, oracle_warm):
     assert mx < TOL, per
 
 
-@pytest.mark.parametrize("name", ["config3", "config5"])
+# config4 = BASELINE configs[3]: 10^6 mixed-phase columns over 8 GPUs -- here ONE of its eight 125 000-column shards (config 3's
+# recipe; the shard of rank 3, i.e. the seed bench.py gives that rank), at the shard size a GPU sees in the 8-GPU run
+@pytest.mark.parametrize("name", ["config3", "config5", "config4"])
 def test_full_size_invariants_split_and_spot_checks(gpu_mixed, oracle_mixed, name):
-    ncol = 100000
-    st0 = getattr(cases, name)(ncol)
+    ncol = 125000 if name == "config4" else 100000
+    st0 = cases.config3(ncol, seed=cases.SEED + 3) if name == "config4" else getattr(cases, name)(ncol)
     dev = _dev(st0)
     ppt, ns = _step(gpu_mixed, dev, nstep=True)
     _check_invariants(dev, ppt)

@@ -58,13 +58,15 @@ def test_fuzz_mixed(gpu_mixed, oracle_mixed, seed, nz, dt):
     assert all(np.isfinite(ref[k]).all() for k in OUT), "oracle produced non-finite values: fix the generator"
     got = {k: v.copy() for k, v in st.items()}
     gppt, _ = gpu_mixed.batch_step_host(got, dt)
-    # Every level is checked: within 5e-7 or 10x the oracle's own ulp-sensitivity there (a branch taken differently
-    # shows up as an O(1) error; rounding amplified by near-total depletion -- floor 1e-5 of the input --, by the
-    # saturation adjustment or by the number-from-mass rebuilds stays far below that on these wild inputs), levels on
-    # the reference's two residue-decided tests against the better of their two outcomes; and >= 99 % of the columns
-    # have every level within 1e-10 (or 10x sensitivity).
-    v = assert_parity(oracle_mixed, st, dt, got, gppt, tol=5e-7, tol_ppt=1e-8, depletion=1e-5, ceiling=1e-5,
-                      max_branch_frac=0.2, min_cols_within=0.99)
+    # Every level is checked.  The bulk: 99.9 % of ALL levels within the north-star tolerance 1e-10, no allowance of any
+    # kind (the 40 000-column campaign, profiles/r03_fuzz_campaign.jsonl, has ~1e-4 of the levels beyond it).  The tail:
+    # every level within 5e-7 or 10x the oracle's own ulp-sensitivity there and none beyond 2e-6 whatever the sensitivity
+    # (campaign worst 4.7e-7: a branch taken differently shows up as an O(1) error; rounding amplified by near-total
+    # depletion -- floor 1e-5 of the input --, by the saturation adjustment or by the number-from-mass rebuilds stays far
+    # below that on these wild inputs), levels on the reference's two residue-decided tests against the better of their two
+    # outcomes; and >= 99 % of the columns have every level within 1e-10 (or 10x sensitivity).
+    v = assert_parity(oracle_mixed, st, dt, got, gppt, tol=5e-7, tol_ppt=1e-8, depletion=1e-5, ceiling=2e-6,
+                      max_branch_frac=0.2, min_cols_within=0.99, quantile=(0.999, 1e-10))
     print("fuzz", seed, v)
 
 
@@ -76,7 +78,8 @@ def test_fuzz_warm(gpu_warm, oracle_warm):
     rppt = oracle_warm.batch_step(ref, 10.0)
     got = {k: v.copy() for k, v in st.items()}
     gppt, _ = gpu_warm.batch_step_host(got, 10.0)
-    assert_parity(oracle_warm, st, 10.0, got, gppt, tol=5e-7, tol_ppt=1e-8, depletion=1e-5, ceiling=1e-5, min_cols_within=0.99)
+    assert_parity(oracle_warm, st, 10.0, got, gppt, tol=5e-7, tol_ppt=1e-8, depletion=1e-5, ceiling=2e-6, min_cols_within=0.99,
+                  quantile=(0.999, 1e-10))
 
 
 def test_fuzz_warm_with_frozen_species_present(gpu_warm, oracle_warm):
@@ -88,5 +91,6 @@ def test_fuzz_warm_with_frozen_species_present(gpu_warm, oracle_warm):
     rppt = oracle_warm.batch_step(ref, 10.0)
     got = {k: v.copy() for k, v in st.items()}
     gppt, _ = gpu_warm.batch_step_host(got, 10.0)
-    assert_parity(oracle_warm, st, 10.0, got, gppt, tol=5e-7, tol_ppt=1e-8, depletion=1e-5, ceiling=1e-5, min_cols_within=0.99)
+    assert_parity(oracle_warm, st, 10.0, got, gppt, tol=5e-7, tol_ppt=1e-8, depletion=1e-5, ceiling=2e-6, min_cols_within=0.99,
+                  quantile=(0.999, 1e-10))
     assert (st["qi"] > 1e-12).any() and np.array_equal(got["qs"] > 0, st["qs"] > 1e-12)   # snow only cleaned, M:1475-1483

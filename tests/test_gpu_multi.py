@@ -70,6 +70,85 @@ def test_device_list_0_0_equals_single_context(name, iiwarm, ncol):
         single.close(); one.close(); two.close()
 
 
+def test_config4_eight_way_partition_on_one_device():
+    """BASELINE configs[3] as the library's multi entry sees it: a 125 000-column shard's worth of config-3-type columns
+    cut eight ways (kidmp_init_multi with the device list (0,)*8: eight contexts, eight host threads, eight pipelines,
+    ranges of 15 625 columns) against ONE context: concatenation equality per column, identical exact sums, identical
+    sanity scan."""
+    from kid_amd import ThompsonMP
+    from kid_amd.thompson import ThompsonMulti, limbs_to_sums, shard_bounds
+    ncol = 125000
+    st = cases.config3(ncol, seed=cases.SEED + 5)
+    a = {k: v.copy() for k, v in st.items()}
+    single = ThompsonMP(iiwarm=False)
+    try:
+        pa, _ = single.batch_step_host(a, 10.0)
+        limbs = single.reduce_ppt_exact(torch.from_numpy(pa).cuda())
+        want_sums = limbs_to_sums(limbs.cpu().numpy())
+        dev = {k: torch.from_numpy(a[k]).cuda() for k in single.SANITY_NEG}
+        want_sanity = single.sanity(dev).cpu().numpy()
+        del dev
+    finally:
+        single.close()
+    eight = ThompsonMulti([0] * 8, iiwarm=False)
+    try:
+        b = {k: v.copy() for k, v in st.items()}
+        pb, _, nb, sums, sanity = eight.batch_step_host(b, 10.0, want_nstep=True, want_sanity=True)
+        for k in OUT:
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(pa, pb)
+        assert np.array_equal(sums, want_sums), (sums, want_sums)
+        assert np.array_equal(sanity, want_sanity), (sanity, want_sanity)
+        assert (nb[:, 0] >= 1).all()
+        sizes = [shard_bounds(ncol, 8, i)[1] - shard_bounds(ncol, 8, i)[0] for i in range(8)]
+        assert sizes == [15625] * 8
+    finally:
+        eight.close()
+
+
+@pytest.mark.parametrize("name,iiwarm,ncol", [("config3", False, 3001), ("config2", True, 64)])
+def test_multi_sanity_scan_equals_unsharded_scan(name, iiwarm, ncol):
+    """kidmp_batch_step_host_multi_diag's sanity15: reduced over the contexts (max of the seven maxima, sum of the eight
+    negative counts) it equals kidmp_sanity_device of the unsharded end state, also with negative entries present."""
+    from kid_amd import ThompsonMP
+    from kid_amd.thompson import ThompsonMulti
+    st = getattr(cases, name)(ncol)
+    st["qr"][5, 3] = -1e-9            # the scan counts negative entries of the END state: block B zeroes these (q <= R1) ...
+    st["qv"][7:9, 100] = -1e-3        # ... and clamps qv to 1e-10, so the counts come out 0 -- the maxima are what differs per shard
+    single, two = ThompsonMP(iiwarm=iiwarm), ThompsonMulti([0, 0], iiwarm=iiwarm)
+    try:
+        a = {k: v.copy() for k, v in st.items()}
+        b = {k: v.copy() for k, v in st.items()}
+        single.batch_step_host(a, 10.0)
+        _, _, _, sums, sanity = two.batch_step_host(b, 10.0, want_sanity=True)
+        dev = {k: torch.from_numpy(a[k]).cuda() for k in single.SANITY_NEG}
+        want = single.sanity(dev).cpu().numpy()
+        assert np.array_equal(sanity, want), (sanity, want)
+        for i, k in enumerate(single.SANITY_MAX):
+            assert sanity[i] == a[k].max(), k
+        # the maxima of the two halves differ (perturbed columns), so the MAX reduction is not trivially one shard's value
+        if name == "config3":
+            half = ncol // 2 + ncol % 2
+            assert a["qr"][:half].max() != a["qr"][half:].max()
+        # a second call without the scan leaves no stale state behind and still returns the sums
+        c = {k: v.copy() for k, v in st.items()}
+        _, _, _, sums2 = two.batch_step_host(c, 10.0)
+        assert np.array_equal(sums, sums2)
+    finally:
+        single.close(); two.close()
+
+
+def test_reserve_is_a_checked_no_op():
+    from kid_amd import KidmpError, ThompsonMP
+    m = ThompsonMP(iiwarm=True)
+    try:
+        m.reserve(1000, 120)
+        with pytest.raises(KidmpError):
+            m.reserve(-1, 120)
+    finally:
+        m.close()
+
+
 def test_multi_entry_optional_arrays_and_errors():
     """The KiD adapter's call (arrays KiD never fills left out) through the multi entry; bad calls fail with a message."""
     from kid_amd import KidmpError, ThompsonMP
