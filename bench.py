@@ -428,7 +428,7 @@ def run_rank(args):
         ncol, kern_s = res["ncol_per_gpu"], res["kernel_ms"] * 1e-3
         algo_bytes = ALGO_BYTES_FP64 if args.arith == "p64" else ALGO_BYTES_FP64 // 2      # fp32 9 616 B
         achieved = algo_bytes * ncol / kern_s
-        fp = shard.model.kernel_fingerprint()
+        fp = shard.model.kernel_fingerprint(args.arith)
         prof = load_pmc_profile(res["name"], ncol, fp, args.arith)
         out = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "frac": achieved / HBM_PEAK, "traffic": None, "traffic_bytes_per_launch": None, "valu_frac": None,

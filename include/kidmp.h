@@ -302,6 +302,8 @@ const char *kidmp_kernel_name(void);
  * "src:<hash of the kernel sources and flags>;vgpr:<n>;lds:<bytes>;scratch:<bytes>".  Profiles under profiles/
  * carry it, so a counter file measured on another build of the kernel is recognised as stale (bench.py). */
 const char *kidmp_kernel_fingerprint(kidmp_ctx *ctx);
+/* The same for the binary32 code objects behind kidmp32_*: arith = KIDMP_ARITH_P32N or KIDMP_ARITH_F32 ("" otherwise). */
+const char *kidmp32_kernel_fingerprint(kidmp_ctx *ctx, int32_t arith);
 
 #ifdef __cplusplus
 }

@@ -878,6 +878,15 @@ const char *kidmp_kernel_fingerprint(kidmp_ctx *ctx)
     return ctx->fingerprint.c_str();
 }
 
+const char *kidmp32_kernel_fingerprint(kidmp_ctx *ctx, int32_t arith)
+{
+    if (!ctx || !ctx->ready || (arith != KIDMP_ARITH_P32N && arith != KIDMP_ARITH_F32)) return "";
+    DeviceGuard guard_(ctx->cfg.device);
+    ctx->fingerprint = arith == KIDMP_ARITH_P32N ? p32n::column_kernel_fingerprint(ctx->cfg.iiwarm != 0)
+                                                 : f32::column_kernel_fingerprint(ctx->cfg.iiwarm != 0);
+    return ctx->fingerprint.c_str();
+}
+
 int64_t kidmp_get_table(kidmp_ctx *ctx, const char *name, double *out, int64_t cap)
 {
     if (!ctx || !ctx->ready || !name) return fail(ctx, KIDMP_ESTATE, "kidmp_get_table: bad context");

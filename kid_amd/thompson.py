@@ -102,6 +102,8 @@ def load_library(path=None):
     L.kidmp_effective_radii_device.argtypes = [_vp, C.c_int64] + [_vp] * 11 + [_vp]
     L.kidmp_kernel_fingerprint.restype = C.c_char_p
     L.kidmp_kernel_fingerprint.argtypes = [_vp]
+    L.kidmp32_kernel_fingerprint.restype = C.c_char_p
+    L.kidmp32_kernel_fingerprint.argtypes = [_vp, C.c_int32]
     L.kidmp_reduce_ppt_exact_device.restype = C.c_int
     L.kidmp_reduce_ppt_exact_device.argtypes = [_vp, C.c_int64, _vp, _vp, _vp]
     L.kidmp_ppt_limbs_to_sums.restype = C.c_int
@@ -415,9 +417,12 @@ class ThompsonMP:
             *[o.data_ptr() for o in out], s))
         return tuple(out)
 
-    def kernel_fingerprint(self):
-        """'src:<hash>;vgpr:<n>;lds:<bytes>;scratch:<bytes>' of this context's nz <= 120 column-step kernel."""
-        return load_library().kidmp_kernel_fingerprint(self._h).decode()
+    def kernel_fingerprint(self, arith="p64"):
+        """'src:<hash>;vgpr:<n>;lds:<bytes>;scratch:<bytes>' of this context's nz <= 120 column-step kernel, in the
+        parity arithmetic (p64) or one of the binary32 ones (p32n, f32)."""
+        if arith == "p64":
+            return load_library().kidmp_kernel_fingerprint(self._h).decode()
+        return load_library().kidmp32_kernel_fingerprint(self._h, {"p32n": 0, "f32": 1}[arith]).decode()
 
     # ---- introspection for parity tests ----
     MATH_FUNCS = ("log", "log10", "exp", "exp10", "sqrt", "cbrt", "pow", "rcp_seed", "div", "ieee_div", "rcp")
