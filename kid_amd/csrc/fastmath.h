@@ -32,6 +32,23 @@ constexpr double LOG10_2 = 0.3010299956639812;
 constexpr double LOG2_10_HI = 3.321928094887362, LOG2_10_LO = 1.661617516973592e-16;
 constexpr double SQRT_HALF = 0.70710678118654757;
 
+// a*b + C for a compile-time constant C, on the device as v_fma_f64 (VOP3) with C in an SGPR pair.  Left to itself the
+// compiler turns a Horner step into v_fmac_f64 (VOP2, addend tied to the destination) and moves the constant into the
+// destination VGPR pair first -- two v_mov_b32, VECTOR instructions, per coefficient (600 of the mixed-phase kernel's 7 500
+// static VALU instructions were such moves).  Scalar moves go to the scalar unit, which has room at three waves per SIMD.
+// Same operation, same rounding.  (gfx9's VOP3 reads ONE scalar operand: a step whose multiplicand is a constant too
+// keeps std::fma.)
+KFM_FN double fma_k(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return std::fma(a, b, c);
+#endif
+}
+
 // x = 2**e * m with m in [sqrt(1/2), sqrt(2)); x positive, finite, normal
 struct Split { double e, m; };
 KFM_FN Split split(double x)
@@ -53,8 +70,8 @@ KFM_FN double ln_mant(double m)
     const double f = m - 1.;                             // exact
     const double s = f / (2. + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * std::fma(w, std::fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * std::fma(w, std::fma(w, std::fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double t1 = w * fma_k(w, std::fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma_k(w, fma_k(w, std::fma(w, Lg7, Lg5), Lg3), Lg1);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     return f - (hfsq - s * (hfsq + R));
@@ -70,8 +87,8 @@ KFM_FN double exp2_small(double r)
                      c13 = 1.3691488853904128e-12;
     const double q = r * r;
     // 2**r = 1 + r*(c1 + c3 q + c5 q^2 ...) + q*(c2 + c4 q + ...): two independent Horner chains in q
-    const double od = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, c13, c11), c9), c7), c5), c3), c1);
-    const double ev = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, c12, c10), c8), c6), c4), c2);
+    const double od = fma_k(q, fma_k(q, fma_k(q, fma_k(q, fma_k(q, std::fma(q, c13, c11), c9), c7), c5), c3), c1);
+    const double ev = fma_k(q, fma_k(q, fma_k(q, fma_k(q, std::fma(q, c12, c10), c8), c6), c4), c2);
     return 1. + std::fma(r, od, q * ev);
 }
 
@@ -83,8 +100,8 @@ KFM_FN double exp_small(double r)
                      d9 = 2.7557319223985893e-06, d10 = 2.755731922398589e-07, d11 = 2.505210838544172e-08,
                      d12 = 2.08767569878681e-09, d13 = 1.6059043836821613e-10;
     const double q = r * r;
-    const double od = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, d13, d11), d9), d7), d5), d3);   // r^3 and up
-    const double ev = std::fma(q, std::fma(q, std::fma(q, std::fma(q, std::fma(q, d12, d10), d8), d6), d4), d2);
+    const double od = fma_k(q, fma_k(q, fma_k(q, fma_k(q, std::fma(q, d13, d11), d9), d7), d5), d3);   // r^3 and up
+    const double ev = fma_k(q, fma_k(q, fma_k(q, fma_k(q, std::fma(q, d12, d10), d8), d6), d4), d2);
     return 1. + (r + q * std::fma(r, od, ev));
 }
 

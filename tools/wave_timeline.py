@@ -12,7 +12,7 @@ import torch
 import bench
 from kid_amd import thompson
 
-assert os.environ.get("KIDMP_DEBUG_STOP") == "7"
+assert os.environ.get("KIDMP_DEBUG_STOP") in ("7", "8")
 name = sys.argv[1]
 ncol = int(sys.argv[2]) if len(sys.argv) > 2 else (10000 if name == "config2" else 100000)
 thompson.load_library(os.path.join(ROOT, "kid_amd", "libkidmp_prof.so"))
@@ -25,7 +25,7 @@ for _ in range(3):
     m.batch_step(d, 10.0, ppt)
 torch.cuda.synchronize()
 t = ppt.cpu().numpy()
-names = ["pass 0", "barrier 1", "pass 1 (own bands)", "barrier 2"]
+names = ["pass 0", "barrier 1", "pass 1 (own bands)", "barrier 2"] if os.environ["KIDMP_DEBUG_STOP"] == "7" else ["pass 3", "pass 4", "barrier 3", "pass 5 (own bands)"]
 print(desc)
 for i, n in enumerate(names):
     x = t[:, i]
