@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round tag (run on the GPU box; results land in gpurun_out/profiles_<tag>):
-#   tools/refresh_profiles.sh r03
+#   tools/refresh_profiles.sh r04
 set -e
 export TMPDIR=/tmp
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 for w in config3 config5 config2; do
@@ -11,7 +11,13 @@ for w in config3 config5 config2; do
   cp gpurun_out/pmc_${tag}_$w.json $out/${tag}_pmc_$w.json
   echo "pmc $w done"
 done
-# the bench reads profiles/<tag>_pmc_<workload>.json for the measured HBM traffic / VALU counts (fingerprint-checked)
+# the binary32 code objects on the precision-sweep workload (BASELINE config 5)
+for a in p32n f32; do
+  bash tools/pmc_profile.sh config5 ${tag}_config5_$a $a > /dev/null
+  cp gpurun_out/pmc_${tag}_config5_$a.json $out/${tag}_pmc_config5_$a.json
+  echo "pmc config5 $a done"
+done
+# the bench reads profiles/<tag>_pmc_<workload>[_<arith>].json for the measured HBM traffic / VALU counts (fingerprint-checked)
 mkdir -p profiles && cp $out/${tag}_pmc_*.json profiles/
 python bench.py > $out/${tag}_bench_default.json
 echo "bench default: $(cut -c1-160 $out/${tag}_bench_default.json)"
