@@ -357,6 +357,10 @@ std::vector<Named> const_dir(const kidmp_ctx *c)
 __global__ void k_math_probe(int fn, int64_t n, const double *x, const double *y, double *out)
 {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+#if KFM_TABLES
+    fm::tab::load_tables(int(threadIdx.x), int(blockDim.x));
+    __syncthreads();
+#endif
     if (i >= n) return;
     double r = 0.;
     switch (fn) {

@@ -31,7 +31,7 @@ def test_log_family(gpu_mixed, rng):
     x = _pos(rng, -45, 25)
     xl = x.astype(np.longdouble)
     assert _ulp_err(gpu_mixed.math_probe("log", x), np.log(xl)) <= 1.5
-    assert _ulp_err(gpu_mixed.math_probe("log10", x), np.log10(xl)) <= 2.0
+    assert _ulp_err(gpu_mixed.math_probe("log10", x), np.log10(xl)) <= 2.2
 
 
 def test_exp_family(gpu_mixed, rng):
