@@ -270,6 +270,10 @@ __global__ void k_effective_radii(int64_t n, RadConsts c, const double *__restri
                                   double *__restrict__ re_qc, double *__restrict__ re_qi, double *__restrict__ re_qs)
 {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+#if KFM_TABLES
+    fm::tab::load_tables(int(threadIdx.x), int(blockDim.x));           // the snow moment below is a fastmath.h power
+    __syncthreads();
+#endif
     if (i >= n) return;
     const double am_r_ = PI * rho_w / 6.0, am_i_ = PI * rho_i / 6.0;
     const double rho = 0.622 * p[i] / (Rgas * t[i] * (qv[i] + 0.622));

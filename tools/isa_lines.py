@@ -5,7 +5,8 @@ thompson_column_step that it was expanded from.
   hipcc <flags of csrc/Makefile> -gline-tables-only --offload-device-only -c thompson_column.hip -o col.o
   clang-offload-bundler --unbundle --type=o --input=col.o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=col.elf
   llvm-objdump -d --no-show-raw-insn col.elf > col.s
-usage: isa_lines.py col.elf col.s <mangled-name fragment> [bucket]     bucket = lines per histogram bin (default 1)"""
+usage: isa_lines.py col.elf col.s <mangled-name fragment> [bucket] [regex]
+       bucket = lines per histogram bin (default 1); regex = only instructions whose disassembly text matches (re.search)"""
 import collections
 import re
 import subprocess
@@ -13,6 +14,7 @@ import sys
 
 elf, path, frag = sys.argv[1:4]
 bucket = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+only = re.compile(sys.argv[5]) if len(sys.argv) > 5 else None
 SYMB = "/opt/rocm/lib/llvm/bin/llvm-symbolizer"
 addrs, ops = [], []
 inside = False
@@ -23,7 +25,7 @@ for line in open(path, errors="ignore"):
     if not inside:
         continue
     m = re.match(r"^\s+([a-z_0-9]+)\s.*//\s*([0-9A-Fa-f]+):", line)
-    if m:
+    if m and (only is None or only.search(line.split("//")[0])):
         ops.append(m.group(1)); addrs.append(int(m.group(2), 16))
 out = subprocess.run([SYMB, "-i", "-e", elf, "--output-style=GNU", "-f", "-s"], input="\n".join("0x%x" % a for a in addrs),
                      capture_output=True, text=True).stdout
