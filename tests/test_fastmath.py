@@ -27,3 +27,25 @@ def test_fastmath_ulp_bounds():
     assert set(got) == set(BOUNDS)
     for name, bound in BOUNDS.items():
         assert got[name] <= bound, f"{name}: {got[name]} ulp > {bound}"
+
+
+def test_math_tables_are_what_the_generator_writes():
+    """kid_amd/csrc/fastmath_tables.h is generated (tools/gen_mathtab.py, 60-digit arithmetic): the committed header must be
+    the generator's output, and the properties the kernel relies on must hold in it."""
+    import re
+    import sys
+    pytest = __import__("pytest")
+    pytest.importorskip("mpmath")
+    hdr = open(os.path.join(ROOT, "kid_amd", "csrc", "fastmath_tables.h")).read()
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "gen_mathtab.py")], text=True)
+    assert out == hdr
+    body = hdr[hdr.index("#define KFM_MATHTAB_INIT"):]
+    vals = [float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)]
+    assert len(vals) == 2 * 64 + 64
+    pairs = list(zip(vals[0:128:2], vals[1:128:2]))
+    assert pairs[40] == (1.0, 0.0)                                   # the bin around 1.0: r = x - 1 exactly, ln c = 0
+    import math
+    for invc, logc in pairs:
+        assert abs(logc + math.log(invc)) <= 1e-16 * max(1.0, abs(logc)) + 1e-17
+    for j, t in enumerate(vals[128:]):
+        assert abs(t / 2.0 ** (j / 64.0) - 1.0) < 3e-16
