@@ -211,7 +211,9 @@ def test_native_real4_kid_build_in_the_reference_native_arithmetic():
     native = np.array([1.530434, 2.218541e-2, 2.693803e-3, 1.060634e6])
     p64 = np.array([1.530434, 2.218719e-2, 2.694135e-3, 1.060568e6])
     print("KAT-B through the Fortran drop-in:", res)
-    assert np.all(np.abs(res["p32n"] / native - 1) < 4e-5), res["p32n"]
+    # (this driver is default REAL like the survey's native probe: it forms the inputs in binary32 itself, and the Python
+    #  twin of it, kat_cases.kat_b_native through tests/test_gpu_precision.py, ends on the same seven digits)
+    assert np.all(np.abs(res["p32n"] / native - 1) < 2.5e-5), res["p32n"]      # measured 4e-7, 4e-6, 1.5e-5, 1.1e-5
     assert np.all(np.abs(res["p32n"][1:] - native[1:]) < 0.5 * np.abs(p64[1:] - native[1:])), res["p32n"]
     assert np.all(np.abs(res["f32"] / native - 1) < 3e-4), res["f32"]
     # the 8-byte build refuses the binary32 arithmetic instead of converting silently

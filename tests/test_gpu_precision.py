@@ -71,12 +71,14 @@ def test_kat_b_native_through_the_p32n_kernel(gpu_warm):
     """the reference AS SHIPPED ends KAT-B (360 warm steps through the adapter) at sum(qc) 2.218541e-2,
     sum(qr) 2.693803e-3, sum(nr) 1.060634e6; its P64 build at 2.218719e-2, 2.694135e-3, 1.060568e6.  The p32n kernel,
     driven like the adapter drives it (state + dt*tendency in binary32), lands near the native numbers, not the P64 ones."""
-    c = kc.kat_b()
+    c = kc.kat_b_native()                      # inputs formed in binary32, as the survey's native probe forms them
     nz, dt = c["nz"], f32(c["dt"])
-    theta, qv = c["theta"].astype(f32), c["qv"].astype(f32)
-    qc, qr, nr = (c["hydro"][0, 0, 0].astype(f32), c["hydro"][0, 1, 0].astype(f32), c["hydro"][1, 1, 0].astype(f32))
-    exner, dz = c["exner"].astype(f32), c["dz"].astype(f32)
-    p = (f32(c["p0"]) * exner ** (f32(1.0) / f32(c["r_on_cp"]))).astype(f32)
+    theta, qv = c["theta"].copy(), c["qv"].copy()
+    qc, qr, nr = (c["hydro"][0, 0, 0].copy(), c["hydro"][0, 1, 0].copy(), c["hydro"][1, 1, 0].copy())
+    exner, dz = c["exner"], c["dz"]
+    m = kc._libm32()                           # p1d = p0*exner**(1./r_on_cp), W:61: REAL**REAL = powf
+    ex = float(f32(1.0) / f32(c["r_on_cp"]))
+    p = (f32(c["p0"]) * np.array([m.powf(float(e), ex) for e in exner], dtype=f32)).astype(f32)
     z = np.zeros(nz, dtype=f32)
     for _ in range(360):
         t = (theta * exner).astype(f32)
@@ -96,5 +98,5 @@ def test_kat_b_native_through_the_p32n_kernel(gpu_warm):
     native, p64 = [2.218541e-2, 2.693803e-3, 1.060634e6], [2.218719e-2, 2.694135e-3, 1.060568e6]
     print("KAT-B p32n kernel:", got)
     for g, n, pp in zip(got, native, p64):
-        assert abs(g / n - 1) < 4e-5, (got, native)
+        assert abs(g / n - 1) < 2.5e-5, (got, native)     # measured 4e-6, 1.5e-5, 1.1e-5 (binary32 special-function units, not libm)
         assert abs(g - n) < 0.5 * abs(pp - n), (g, n, pp)
