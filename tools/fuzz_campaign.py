@@ -27,6 +27,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=40)
 ap.add_argument("--ncol", type=int, default=1000)
 ap.add_argument("--first-seed", type=int, default=100)
+ap.add_argument("--warm-seeds", type=int, default=10, help="additional seeds through the warm-rain kernel (iiwarm contexts): even ones "
+                "with the frozen species zeroed (the normal KiD warm case), odd ones with ice, snow and graupel present")
 args = ap.parse_args()
 
 NZ = (64, 128, 120, 77, 120, 200, 120, 33)
@@ -54,3 +56,28 @@ for i in range(args.seeds):
 tot["kernel_fingerprint"] = m.kernel_fingerprint("p64")
 print(json.dumps(dict(total=tot)), flush=True)
 m.close(); o.close()
+
+if args.warm_seeds:
+    m, o = ThompsonMP(iiwarm=True), Oracle(iiwarm=True, nthreads=min(os.cpu_count() or 1, 16))
+    wt = dict(columns=0, levels=0, columns_with_a_level_beyond=0, levels_beyond=0, levels_gt_1e7=0, worst=0.0)
+    for i in range(args.warm_seeds):
+        seed = args.first_seed + 1000 + i
+        nz, dt = NZ[i % len(NZ)], DT[i % len(DT)]
+        st = fuzz_columns(args.ncol, nz, seed)
+        if i % 2 == 0:
+            for k in ("qi", "ni", "qs", "qg"):
+                st[k][:] = 0.0
+        got = {k: v.copy() for k, v in st.items()}
+        gppt, _ = m.batch_step_host(got, dt)
+        cmp = branch_aware_compare(o, st, dt, got, gppt, depletion=1e-5)
+        err, sens = cmp["err"], cmp["sens"]
+        beyond = err > np.maximum(1e-10, 10.0 * sens)
+        rec = dict(warm_seed=seed, nz=nz, dt=dt, frozen_species_present=bool(i % 2), worst=float(err.max()),
+                   cols_within_tol=float((~beyond).all(axis=1).mean()), levels_beyond=int(beyond.sum()),
+                   levels_gt_1e7=int((err > 1e-7).sum()), q999=float(np.quantile(err, 0.999)), precip_worst=float(cmp["ppt_err"].max()))
+        print(json.dumps(rec), flush=True)
+        wt["columns"] += args.ncol; wt["levels"] += int(err.size); wt["columns_with_a_level_beyond"] += int(beyond.any(axis=1).sum())
+        wt["levels_beyond"] += rec["levels_beyond"]; wt["levels_gt_1e7"] += rec["levels_gt_1e7"]; wt["worst"] = max(wt["worst"], rec["worst"])
+    wt["kernel_fingerprint"] = m.kernel_fingerprint("p64")
+    print(json.dumps(dict(total_warm=wt)), flush=True)
+    m.close(); o.close()
