@@ -149,13 +149,16 @@ void host_init(int iiwarm, int l_sediment, double set_Nc, Consts &c, Bins &b)
         const int n = i < 15 ? i : 14;
         c.lds_tab[0 * 16 + i] = c.ccg[0][n];  c.lds_tab[1 * 16 + i] = c.ccg[1][n];  c.lds_tab[2 * 16 + i] = c.ocg1[n];
         c.lds_tab[3 * 16 + i] = c.ocg2[n];    c.lds_tab[4 * 16 + i] = c.cce[1][n];  c.lds_tab[5 * 16 + i] = c.dcg_fac[n];
+        // (ccg(2,n)*ocg1(n))**obmr: rc/(am_r*nc) = ccg(2,n)*ocg1(n)/lamc**3, so the mean-size diameter of M:1693 is this
+        // constant over lamc -- the form the reference itself gives Dc_g (M:1699) -- instead of a second cube root
+        c.lds_tab[6 * 16 + i] = std::pow(c.ccg[1][n] * c.ocg1[n], c.obmr);
     }
     for (int t = 0; t < 32; ++t) {
         const int n = t - 16, m = n < 0 ? -n : n;
         static const double sq[5] = {10., 100., 1.e4, 1.e8, 1.e16};
         double T = 1.;                                        // 10**m, exact (m <= 16): every partial product is a power of ten
         for (int b = 0; b < 5; ++b) if (m & (1 << b)) T *= sq[b];
-        c.lds_tab[96 + t] = n <= 0 ? T : 1. / T;
+        c.lds_tab[112 + t] = n <= 0 ? T : 1. / T;
     }
 
     // axes, M:215-315

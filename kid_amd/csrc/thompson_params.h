@@ -77,10 +77,10 @@ struct Consts {
     double t_Nc1;
     int32_t nic1, pad_;
     // what the column kernel copies into LDS at workgroup start, as one flat table (one load per thread):
-    // [0..95]   six rows of 16 indexed by nu_c-1 (entry 15 repeats 14): ccg(1,:), ccg(2,:), ocg1, ocg2, cce(2,:), dcg_fac
-    // [96..127] 10**-n for n = -16 .. 15: the decade finder's scale factors (exact powers of ten, or their
+    // [0..111]  seven rows of 16 indexed by nu_c-1 (entry 15 repeats 14): ccg(1,:), ccg(2,:), ocg1, ocg2, cce(2,:), dcg_fac, (ccg(2,:)*ocg1)**obmr
+    // [112..143] 10**-n for n = -16 .. 15: the decade finder's scale factors (exact powers of ten, or their
     //           correctly rounded reciprocals)
-    double lds_tab[128];
+    double lds_tab[144];
     // graupel intercept (M:1639-1647) of a level without graupel (rg <= 5.E-5) and without supercooled rain above k_0:
     // a constant of the scheme, evaluated once per arithmetic variant ON THE DEVICE by the kernel's own function
     // (upload_consts), so that it carries exactly the bits the per-level evaluation would produce
