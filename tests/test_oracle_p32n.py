@@ -10,6 +10,8 @@ reproduces the recorded native digits of KAT-B: all four sums within one unit of
 a REAL SUM of 120 terms is itself uncertain by that much in its seventh digit, and the survey's sums were such).  KAT-A
 mixed (tables built with P64 constants here, chaotic M:3596 levels on the way) lands within 2.1e-5 (sum qi) and 7e-7
 (rain at call 200)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -60,6 +62,19 @@ def test_kat_b_native_360_steps_through_the_adapter(oracle_warm):
         assert abs(g / n - 1) < 5e-7, (got, native)                 # one unit of the seventh digit (measured 1.3e-7 ... 3.3e-7)
     for g, n, p in zip(got[1:], native[1:], p64[1:]):
         assert abs(g - n) < 0.02 * abs(p - n), (g, n, p)            # fifty times closer to native than P64 is
+
+
+def test_native_inputs_are_the_committed_ones():
+    """kat_b_native / kat_a_native call this host's powf / expf: the binary32 profiles they form are frozen in
+    tests/golden/kat_native_inputs.npz (written on the image the native digits were matched on, glibc 2.35), so a libm
+    whose binary32 functions round differently shows up here and not as a shifted seventh digit above."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kat_native_inputs.npz"))
+    b, a = kc.kat_b_native(), kc.kat_a_native(True)
+    for k in ("theta", "exner", "qv"):
+        assert np.array_equal(b[k], g["b_" + k]), k
+    assert f32(b["r_on_cp"]) == g["b_r_on_cp"]
+    for k in ("t", "p", "qv", "nc"):
+        assert np.array_equal(a[k], g["a_" + k]), k
 
 
 def test_kat_b_inputs_formed_in_binary64_miss_the_native_digits(oracle_warm):
