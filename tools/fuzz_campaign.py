@@ -29,7 +29,11 @@ ap.add_argument("--ncol", type=int, default=1000)
 ap.add_argument("--first-seed", type=int, default=100)
 ap.add_argument("--warm-seeds", type=int, default=10, help="additional seeds through the warm-rain kernel (iiwarm contexts): even ones "
                 "with the frozen species zeroed (the normal KiD warm case), odd ones with ice, snow and graupel present")
+ap.add_argument("--lib", default=None, help="another build of libkidmp.so (A/B of the parity tail between kernels)")
 args = ap.parse_args()
+if args.lib:
+    import kid_amd
+    kid_amd.load_library(args.lib)
 
 NZ = (64, 128, 120, 77, 120, 200, 120, 33)
 DT = (5.0, 10.0, 10.0, 10.0, 2.0, 10.0, 20.0, 10.0)
